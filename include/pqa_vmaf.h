@@ -1,0 +1,163 @@
+/*
+ * pqa_vmaf.h -- C ABI of the MI355X-native VMAF feature engine (libpqa_vmaf.so).
+ *
+ * Drop-in boundary.  In the reference (yoseph007/PQA2) the whole scoring hot path is three child
+ * processes started by VMAFAnalyzer.analyze_videos():
+ *     subprocess.Popen([ffmpeg, ..., "-lavfi", "libvmaf=..."])      app/vmaf_analyzer.py:406-419,446
+ *     subprocess.run([ffmpeg, ..., "-lavfi", "psnr=stats_file=..."]) app/vmaf_analyzer.py:1027-1045
+ *     subprocess.run([ffmpeg, ..., "-lavfi", "ssim=stats_file=..."]) app/vmaf_analyzer.py:1057-1075
+ * This library sits where those calls are: the host feeds decoded planes, the library returns one
+ * fixed-size feature record per frame, and the host (Python, as in the reference) applies the
+ * bundled models/vmaf_*.json SVM, pools, and writes the libvmaf-format JSON / stats files that
+ * _parse_vmaf_results (app/vmaf_analyzer.py:628-964) reads back.  INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns PQA_OK (0) or a
+ * negative pqa_status; pqa_last_error() explains the most recent failure.  The caller owns every
+ * buffer it passes in; the library owns all device memory it allocates.  A context is
+ * single-threaded (mirrors VMAFAnalyzer._process_lock, app/vmaf_analyzer.py:29,251); the only call
+ * legal from another thread is pqa_cancel() (mirrors terminate_analysis, app/vmaf_analyzer.py:139).
+ * One context per GPU.
+ */
+#ifndef PQA_VMAF_H
+#define PQA_VMAF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define PQA_API __attribute__((visibility("default")))
+#else
+#define PQA_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pqa_status {
+  PQA_OK = 0,
+  PQA_EINVAL = -1,     /* bad argument / unsupported geometry */
+  PQA_EDEVICE = -2,    /* HIP runtime failure (text in pqa_last_error) */
+  PQA_ENOMEM = -3,     /* host or device allocation failed */
+  PQA_ECANCELLED = -4, /* pqa_cancel() was called; pqa_reset() re-arms the context */
+  PQA_ESTATE = -5      /* call sequence error (e.g. collecting frames never submitted) */
+} pqa_status;
+
+/* feature mask: which extractors run per frame */
+enum {
+  PQA_FEAT_VIF = 1u << 0,    /* libvmaf float VIF, 4 scales        (libvmaf= call site, :377-419) */
+  PQA_FEAT_ADM = 1u << 1,    /* libvmaf float ADM, 4 scales        (same call site)               */
+  PQA_FEAT_MOTION = 1u << 2, /* libvmaf motion (SAD of blurred ref) (same call site)              */
+  PQA_FEAT_PSNR = 1u << 3,   /* FFmpeg psnr filter: per-plane SSE   (:1027-1034)                  */
+  PQA_FEAT_SSIM = 1u << 4,   /* FFmpeg ssim filter: per-plane SSIM  (:1057-1064)                  */
+  PQA_FEAT_VMAF = PQA_FEAT_VIF | PQA_FEAT_ADM | PQA_FEAT_MOTION,
+  PQA_FEAT_ALL = PQA_FEAT_VMAF | PQA_FEAT_PSNR | PQA_FEAT_SSIM
+};
+
+/* One record = PQA_RECORD_DOUBLES 8-byte slots per frame. */
+enum {
+  PQA_REC_VIF_NUM = 0,  /* [4] vif numerator per scale                                        */
+  PQA_REC_VIF_DEN = 4,  /* [4] vif denominator per scale     (vif_scale_s = num/den)           */
+  PQA_REC_ADM_NUM = 8,  /* [4] adm numerator per scale                                        */
+  PQA_REC_ADM_DEN = 12, /* [4] adm denominator per scale     (adm2 = sum num / sum den)        */
+  PQA_REC_MOTION = 16,  /*     motion_i (motion2 is a host-side min over neighbours)           */
+  PQA_REC_SSIM = 17,    /* [3] FFmpeg ssim Y, U, V                                            */
+  PQA_REC_SSE = 20,     /* [3] FFmpeg psnr SSE Y, U, V: uint64 bit-cast into the slot (exact)   */
+  PQA_REC_RESERVED = 23,
+  PQA_RECORD_DOUBLES = 24
+};
+
+typedef struct pqa_config {
+  uint32_t struct_size;        /* sizeof(pqa_config), for ABI growth                              */
+  int32_t device;              /* HIP device ordinal                                              */
+  uint32_t width, height;      /* luma size, both >= 16                                           */
+  uint32_t bit_depth;          /* 8, 10 or 12 (samples > 8 bit are little-endian uint16)          */
+  uint32_t n_planes;           /* 1 = luma only, 3 = Y,U,V (needed for chroma PSNR/SSIM)          */
+  uint32_t chroma_hshift;      /* log2 horizontal chroma subsampling (4:2:0 -> 1)                 */
+  uint32_t chroma_vshift;      /* log2 vertical chroma subsampling   (4:2:0 -> 1)                 */
+  uint32_t features;           /* PQA_FEAT_* mask                                                 */
+  uint32_t max_batch;          /* frames per kernel launch (0 -> default 8)                       */
+  uint32_t result_capacity;    /* records kept on the device, ring indexed by frame_index
+                                  (0 -> default 16384)                                            */
+  uint32_t n_subsample;        /* libvmaf n_subsample (:379): VIF/ADM on frames i % k == 0 only;
+                                  motion on every frame (0/1 -> every frame)                      */
+  double vif_enhn_gain_limit;  /* 100.0 default; 1.0 for *neg models (feature_opts_dicts)         */
+  double adm_enhn_gain_limit;  /* 100.0 default; 1.0 for *neg models                              */
+} pqa_config;
+
+/* A clip already resident in device memory (HBM): frame f of plane p starts at
+ * plane[p] + f * frame_pitch[p]; rows are row_pitch[p] bytes apart.  Pitches are in BYTES. */
+typedef struct pqa_device_clip {
+  const void* plane[3];
+  int64_t row_pitch[3];
+  int64_t frame_pitch[3];
+} pqa_device_clip;
+
+typedef struct pqa_ctx pqa_ctx;
+
+/* Library / record introspection. */
+PQA_API const char* pqa_version(void);
+PQA_API int pqa_record_doubles(void);
+
+/* Fill cfg with defaults (8-bit 4:2:0, PQA_FEAT_VMAF, gain limits 100). */
+PQA_API void pqa_config_init(pqa_config* cfg, uint32_t width, uint32_t height);
+
+/* Create / destroy.  Replaces process start-up of the ffmpeg child (app/vmaf_analyzer.py:446). */
+PQA_API int pqa_create(const pqa_config* cfg, pqa_ctx** out);
+PQA_API void pqa_destroy(pqa_ctx* ctx);
+
+/* Run all work of this context on an existing HIP stream (e.g. torch's current stream).
+ * NULL restores the context's own stream. */
+PQA_API int pqa_set_stream(pqa_ctx* ctx, void* hip_stream);
+
+/* Submit one decoded frame pair from HOST memory.  planes[p] / strides[p] (bytes) for p < n_planes.
+ * The library copies into pinned staging, uploads on a copy stream and launches kernels once
+ * max_batch frames are pending (or at pqa_collect / pqa_flush).  Frames must arrive in increasing,
+ * consecutive frame_index order within a clip; motion of the first submitted frame is 0 unless
+ * pqa_set_motion_halo() supplied its predecessor.
+ * Replaces one frame's worth of the libvmaf/psnr/ssim filter graph input. */
+PQA_API int pqa_submit(pqa_ctx* ctx, int64_t frame_index, const void* const ref_planes[3], const int64_t ref_strides[3],
+               const void* const dis_planes[3], const int64_t dis_strides[3]);
+
+/* Submit n_frames consecutive frame pairs that are ALREADY in device memory (no copies).
+ * prev_ref_luma (nullable, device pointer, prev_row_pitch bytes) is the reference luma of frame
+ * first_index-1 -- the one-frame halo a frame-sharded rank needs for motion.  When NULL the context
+ * continues from the last frame it saw if that was first_index-1, else motion(first_index) = 0. */
+PQA_API int pqa_submit_device(pqa_ctx* ctx, int64_t first_index, int32_t n_frames, const pqa_device_clip* ref,
+                      const pqa_device_clip* dis, const void* prev_ref_luma, int64_t prev_row_pitch);
+
+/* Host-memory variant of the halo for the pqa_submit path. */
+PQA_API int pqa_set_motion_halo(pqa_ctx* ctx, const void* prev_ref_luma_host, int64_t row_stride);
+
+/* Launch whatever pqa_submit has pending (partial batch). */
+PQA_API int pqa_flush(pqa_ctx* ctx);
+
+/* Wait for all submitted work, then copy `count` records starting at frame first_index into
+ * records[count][PQA_RECORD_DOUBLES].  Replaces reading the libvmaf JSON log / stats files. */
+PQA_API int pqa_collect(pqa_ctx* ctx, int64_t first_index, int32_t count, double* records);
+
+/* Wait for all submitted work without collecting. */
+PQA_API int pqa_sync(pqa_ctx* ctx);
+
+/* Thread-safe: makes every later (and the current, between batches) submit/collect return
+ * PQA_ECANCELLED.  Mirrors VMAFAnalyzer.terminate_analysis (app/vmaf_analyzer.py:139-151). */
+PQA_API int pqa_cancel(pqa_ctx* ctx);
+
+/* Clear the cancel flag and the motion continuity state (start of a new clip). */
+PQA_API int pqa_reset(pqa_ctx* ctx);
+
+/* Text of the most recent failure on this context (ctx == NULL: last pqa_create failure). */
+PQA_API const char* pqa_last_error(const pqa_ctx* ctx);
+
+/* Measurement hooks (bench.py): HIP-event timing of individual kernels on the context's stream.
+ * kernel ids: 0..3 vif_stat scale s, 4..6 vif_decimate to scale 1..3, 7..10 adm scale s,
+ * 11 motion, 12 sse, 13 ssim, 14 finalize. */
+enum { PQA_PROF_KERNELS = 15 };
+PQA_API int pqa_profile_enable(pqa_ctx* ctx, int on);
+PQA_API int pqa_profile_read(pqa_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches, uint64_t* frames);
+PQA_API const char* pqa_profile_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQA_VMAF_H */

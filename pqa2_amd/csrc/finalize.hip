@@ -1,0 +1,79 @@
+// Second-stage reduction: every per-tile partial of a batch -> one 24-slot record per frame.
+// One workgroup per frame walks each partial array in a FIXED order (thread-strided, then the same
+// shuffle/LDS tree), so a frame's record does not depend on batch size, launch order or GPU count:
+// 1-, 2-, 4- and 8-GPU runs are bit-identical.  Record layout: include/pqa_vmaf.h (PQA_REC_*).
+#include "kernels.h"
+#include "pqa_device.h"
+
+namespace pqa {
+namespace {
+
+__device__ double reduce_strided(const double* p, int n, int stride, double* red) {
+  double acc[1] = {0.0};
+  for (int i = threadIdx.x; i < n; i += kBlock) acc[0] += p[(int64_t)i * stride];
+  __syncthreads();  // red reuse
+  block_sum<1>(acc, red);
+  return acc[0];  // valid in thread 0
+}
+
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) {
+  __shared__ double red[4];
+  __shared__ unsigned long long redu[4];
+  const int fr = blockIdx.x;
+  const int row = (int)(((int64_t)a.slot_base + (int64_t)fr * a.slot_step) % a.capacity);
+  double* rec = a.records + (int64_t)row * a.record_stride;
+  const int tid = threadIdx.x;
+
+  if (a.has_vif) {
+    for (int s = 0; s < 4; ++s) {
+      const double* p = a.vif_part[s] + (int64_t)fr * a.vif_tiles[s] * 2;
+      const double num = reduce_strided(p, a.vif_tiles[s], 2, red);
+      const double den = reduce_strided(p + 1, a.vif_tiles[s], 2, red);
+      if (tid == 0) { rec[0 + s] = num; rec[4 + s] = den; }
+    }
+  }
+  if (a.has_adm) {
+    for (int s = 0; s < 4; ++s) {
+      const double* p = a.adm_part[s] + (int64_t)fr * a.adm_tiles[s] * 6;
+      double q[6];
+      for (int i = 0; i < 6; ++i) q[i] = reduce_strided(p + i, a.adm_tiles[s], 6, red);
+      if (tid == 0) {
+        // adm_cm_s / adm_csf_den_scale_s epilogue: sum over orientations of cbrt(sum) + cbrt(area/32)
+        const double area_term = cbrt((double)(a.adm_area[s] / 32.0f));
+        rec[8 + s] = cbrt(q[0]) + cbrt(q[1]) + cbrt(q[2]) + 3.0 * area_term;
+        rec[12 + s] = cbrt(q[3]) + cbrt(q[4]) + cbrt(q[5]) + 3.0 * area_term;
+      }
+    }
+  }
+  if (a.has_motion) {
+    const double sad = reduce_strided(a.motion_part + (int64_t)fr * a.motion_tiles, a.motion_tiles, 1, red);
+    if (tid == 0) rec[16] = sad * a.motion_norm;
+  }
+  for (int pl = 0; pl < a.n_ssim_planes; ++pl) {
+    const double s = reduce_strided(a.ssim_part[pl] + (int64_t)fr * a.ssim_tiles[pl], a.ssim_tiles[pl], 1, red);
+    if (tid == 0) rec[17 + pl] = s * a.ssim_norm[pl];
+  }
+  for (int pl = 0; pl < a.n_sse_planes; ++pl) {
+    const unsigned long long* p = a.sse_part[pl] + (int64_t)fr * kSseBlocksPerPlane;
+    unsigned long long v = tid < kSseBlocksPerPlane ? p[tid] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) redu[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long sse = (redu[0] + redu[1]) + (redu[2] + redu[3]);
+      reinterpret_cast<unsigned long long*>(rec)[20 + pl] = sse;  // integer, bit-cast into the slot
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_finalize(hipStream_t stream, const FinalizeArgs& args) {
+  if (args.n_frames <= 0) return hipSuccess;
+  hipLaunchKernelGGL(finalize_kernel, dim3(args.n_frames), dim3(kBlock), 0, stream, args);
+  return hipGetLastError();
+}
+
+}  // namespace pqa

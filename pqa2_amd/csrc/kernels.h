@@ -1,0 +1,97 @@
+// Host-side launch interface of the gfx950 feature kernels.  All pointers are device pointers,
+// pitches are in ELEMENTS of the plane's sample type.  Every launcher is asynchronous on `stream`
+// and allocates nothing (workspaces come from the context), so a caller may capture them in a
+// hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pqa {
+
+enum Elem : int { ELEM_U8 = 0, ELEM_U16 = 1, ELEM_F32 = 2 };
+
+// A run of equally-shaped planes: frame f lives at base + f * frame_pitch.
+struct PlaneRun {
+  const void* base;
+  int64_t row_pitch;    // elements
+  int64_t frame_pitch;  // elements
+};
+
+struct MutPlaneRun {
+  void* base;
+  int64_t row_pitch;
+  int64_t frame_pitch;
+};
+
+// ---- VIF ------------------------------------------------------------------------------------
+// Tile geometry of the statistic kernel at a scale (filter widths 17/9/5/3).
+int vif_tile_w(int scale);
+constexpr int kVifTileH = 16;
+inline int vif_tiles_x(int scale, int w) { return (w + vif_tile_w(scale) - 1) / vif_tile_w(scale); }
+inline int vif_tiles_y(int h) { return (h + kVifTileH - 1) / kVifTileH; }
+
+// partials: [n_frames][tiles][2] doubles (num, den), tiles = tiles_x * tiles_y.
+hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
+                           int w, int h, float inv_scale, float gain_limit, double* partials);
+
+// Filters (w x h) planes with the NEXT scale's kernel and keeps even samples -> (w/2 x h/2) f32.
+hipError_t launch_vif_decimate(hipStream_t stream, int dst_scale, Elem elem, PlaneRun ref, PlaneRun dis,
+                               int n_frames, int w, int h, float inv_scale, MutPlaneRun dst_ref,
+                               MutPlaneRun dst_dis);
+
+// ---- ADM ------------------------------------------------------------------------------------
+constexpr int kAdmTileW = 64, kAdmTileH = 16;
+inline int adm_tiles_x(int band_w) { return (band_w + kAdmTileW - 1) / kAdmTileW; }
+inline int adm_tiles_y(int band_h) { return (band_h + kAdmTileH - 1) / kAdmTileH; }
+
+// One ADM scale: db2 DWT of (w x h) planes -> decouple -> CSF -> contrast masking.
+// partials: [n_frames][tiles][6] doubles (num h,v,d cube sums; den h,v,d cube sums).
+// ll_ref/ll_dis receive the approximation band (ceil(w/2) x ceil(h/2)) for the next scale
+// (base may be null at the last scale).
+hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
+                            int w, int h, float inv_scale, float gain_limit, MutPlaneRun ll_ref,
+                            MutPlaneRun ll_dis, double* partials);
+
+// ---- motion ---------------------------------------------------------------------------------
+constexpr int kMotionTileW = 120, kMotionTileH = 16;
+inline int motion_tiles(int w, int h) {
+  return ((w + kMotionTileW - 1) / kMotionTileW) * ((h + kMotionTileH - 1) / kMotionTileH);
+}
+// SAD of the 5-tap-blurred reference luma of frame f against frame f-1.  Frame 0 of the run uses
+// `prev0` (may be null: then its partials are zero).  partials: [n_frames][tiles] doubles.
+hipError_t launch_motion(hipStream_t stream, Elem elem, PlaneRun ref, const void* prev0, int64_t prev0_row_pitch,
+                         int n_frames, int w, int h, float inv_scale, double* partials);
+
+// ---- PSNR (FFmpeg psnr filter) and SSIM (FFmpeg ssim filter) ----------------------------------
+constexpr int kSseBlocksPerPlane = 256;
+// partials: [n_frames][kSseBlocksPerPlane] uint64 SSE
+hipError_t launch_sse(hipStream_t stream, Elem elem, PlaneRun a, PlaneRun b, int n_frames, int w, int h,
+                      unsigned long long* partials);
+
+constexpr int kSsimTileBW = 32, kSsimTileBH = 8;  // tile = 32 x 8 windows (4x4-block grid)
+inline int ssim_tiles(int w, int h) {
+  const int ww = (w >> 2) - 1, wh = (h >> 2) - 1;
+  if (ww < 1 || wh < 1) return 0;
+  return ((ww + kSsimTileBW - 1) / kSsimTileBW) * ((wh + kSsimTileBH - 1) / kSsimTileBH);
+}
+// main = distorted, ref = reference (order of the filter's inputs).  partials: [n_frames][tiles] doubles.
+hipError_t launch_ssim(hipStream_t stream, Elem elem, PlaneRun main, PlaneRun ref, int n_frames, int w, int h,
+                       int max_value, double* partials);
+
+// ---- finalize -------------------------------------------------------------------------------
+// Fixed-order reduction of every partial array of a batch into per-frame records.
+struct FinalizeArgs {
+  int n_frames;
+  int has_vif, has_adm, has_motion, n_sse_planes, n_ssim_planes;
+  const double* vif_part[4];   int vif_tiles[4];
+  const double* adm_part[4];   int adm_tiles[4];   float adm_area[4];  // cropped-window area per scale
+  const double* motion_part;   int motion_tiles;   double motion_norm;  // 1/(w*h)
+  const unsigned long long* sse_part[3];
+  const double* ssim_part[3];  int ssim_tiles[3];  double ssim_norm[3]; // 1/(windows)
+  double* records;             // [capacity][record_stride] ring
+  int slot_base, slot_step, capacity;  // record row of batch frame f = (slot_base + f*slot_step) % capacity
+  int record_stride;
+};
+hipError_t launch_finalize(hipStream_t stream, const FinalizeArgs& args);
+
+}  // namespace pqa

@@ -1,0 +1,696 @@
+// C ABI of libpqa_vmaf.so: context, workspaces, batching, host staging, profiling hooks.
+// Declarations and the reference interfaces each entry point replaces: include/pqa_vmaf.h.
+#include "../../include/pqa_vmaf.h"
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace pqa;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Level {
+  int w = 0, h = 0;
+  int64_t pitch = 0, frame_pitch = 0;  // elements (float)
+  float* ref = nullptr;
+  float* dis = nullptr;
+};
+
+struct Half {
+  uint8_t* pinned = nullptr;
+  uint8_t* dev = nullptr;
+  hipEvent_t copied = nullptr, computed = nullptr;
+  bool copied_pending = false, computed_pending = false;
+};
+
+struct ProfEv {
+  hipEvent_t a, b;
+  int id, frames;
+};
+
+}  // namespace
+
+struct pqa_ctx {
+  pqa_config cfg{};
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+  Elem elem = ELEM_U8;
+  int esize = 1;
+  float inv_scale = 1.0f;
+  int pw[3] = {0, 0, 0}, ph[3] = {0, 0, 0};
+  int n_planes = 1;
+  int B = 8, capacity = 16384, k_sub = 1;
+  Level vif_lv[4], adm_lv[4];
+  double* vif_part[4] = {};
+  int vif_tiles[4] = {};
+  double* adm_part[4] = {};
+  int adm_tiles[4] = {};
+  float adm_area[4] = {};
+  double* motion_part = nullptr;
+  int motion_tiles_n = 0;
+  unsigned long long* sse_part[3] = {};
+  double* ssim_part[3] = {};
+  int ssim_tiles_n[3] = {};
+  double ssim_norm[3] = {};
+  double* records = nullptr;
+  // motion continuity
+  uint8_t* last_luma = nullptr;
+  int64_t last_luma_pitch = 0;  // bytes
+  int64_t last_index = -1;
+  bool have_last = false, halo_armed = false;
+  // host staging (pqa_submit path)
+  Half half[2];
+  int cur_half = 0, pending = 0;
+  int64_t pending_first = 0;
+  size_t slot_bytes = 0;
+  size_t plane_off[2][3] = {};
+  int64_t slot_row_pitch[3] = {};
+  bool staging_ready = false;
+  std::atomic<int> cancelled{0};
+  std::string err;
+  std::vector<void*> allocs;
+  // profiling
+  bool prof = false;
+  std::vector<ProfEv> evs;
+  double prof_ms[PQA_PROF_KERNELS] = {};
+  uint64_t prof_n[PQA_PROF_KERNELS] = {}, prof_frames[PQA_PROF_KERNELS] = {};
+};
+
+namespace {
+
+int fail(pqa_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail((c), e_ == hipErrorOutOfMemory ? PQA_ENOMEM : PQA_EDEVICE, "%s failed: %s", #expr, \
+                  hipGetErrorString(e_));                                                        \
+  } while (0)
+
+template <typename T>
+int dev_alloc(pqa_ctx* c, T** out, size_t count) {
+  void* p = nullptr;
+  if (count == 0) count = 1;
+  HIPCHK(c, hipMalloc(&p, count * sizeof(T)));
+  c->allocs.push_back(p);
+  *out = (T*)p;
+  return PQA_OK;
+}
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+static const char* kProfNames[PQA_PROF_KERNELS] = {
+    "vif_stat_s0", "vif_stat_s1", "vif_stat_s2", "vif_stat_s3", "vif_decimate_s1", "vif_decimate_s2",
+    "vif_decimate_s3", "adm_scale_s0", "adm_scale_s1", "adm_scale_s2", "adm_scale_s3", "motion", "sse",
+    "ssim", "finalize"};
+
+struct ProfScope {
+  pqa_ctx* c;
+  ProfEv ev{};
+  bool on;
+  ProfScope(pqa_ctx* ctx, int id, int frames) : c(ctx), on(ctx->prof) {
+    if (!on) return;
+    ev.id = id; ev.frames = frames;
+    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+    hipEventRecord(ev.a, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(ev.b, c->stream);
+    c->evs.push_back(ev);
+  }
+};
+
+void prof_drain(pqa_ctx* c) {
+  for (auto& e : c->evs) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      c->prof_ms[e.id] += ms;
+      c->prof_n[e.id] += 1;
+      c->prof_frames[e.id] += e.frames;
+    }
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  c->evs.clear();
+}
+
+// ---- the batch: every kernel for n consecutive device-resident frames -------------------------
+int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, const pqa_device_clip* dis,
+                  const void* prev, int64_t prev_pitch_bytes) {
+  const uint32_t feat = c->cfg.features;
+  const int es = c->esize;
+  for (int p = 0; p < c->n_planes; ++p) {
+    if (ref->row_pitch[p] % es || dis->row_pitch[p] % es || ref->frame_pitch[p] % es || dis->frame_pitch[p] % es)
+      return fail(c, PQA_EINVAL, "plane %d pitch is not a multiple of the sample size", p);
+    if (!ref->plane[p] || !dis->plane[p]) return fail(c, PQA_EINVAL, "plane %d pointer is null", p);
+  }
+  const PlaneRun rY{ref->plane[0], ref->row_pitch[0] / es, ref->frame_pitch[0] / es};
+  const PlaneRun dY{dis->plane[0], dis->row_pitch[0] / es, dis->frame_pitch[0] / es};
+  const int w = c->pw[0], h = c->ph[0];
+  hipStream_t st = c->stream;
+
+  // frames that get spatial features (libvmaf n_subsample: index % k == 0)
+  const int k = c->k_sub;
+  int e0 = 0, sp_n = n;
+  if (k > 1) {
+    e0 = (int)((k - first % k) % k);
+    sp_n = e0 < n ? (n - e0 + k - 1) / k : 0;
+  }
+  const auto sub = [&](PlaneRun r) {
+    return PlaneRun{(const uint8_t*)r.base + (int64_t)e0 * r.frame_pitch * es, r.row_pitch, r.frame_pitch * k};
+  };
+  const PlaneRun rYs = k > 1 ? sub(rY) : rY, dYs = k > 1 ? sub(dY) : dY;
+
+  if ((feat & PQA_FEAT_VIF) && sp_n > 0) {
+    PlaneRun cr = rYs, cd = dYs;
+    Elem ce = c->elem;
+    int cw = w, ch = h;
+    for (int s = 0; s < 4; ++s) {
+      if (s > 0) {
+        Level& L = c->vif_lv[s];
+        ProfScope ps(c, 3 + s, sp_n);
+        HIPCHK(c, launch_vif_decimate(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
+                                      MutPlaneRun{L.ref, L.pitch, L.frame_pitch},
+                                      MutPlaneRun{L.dis, L.pitch, L.frame_pitch}));
+        cr = PlaneRun{L.ref, L.pitch, L.frame_pitch};
+        cd = PlaneRun{L.dis, L.pitch, L.frame_pitch};
+        ce = ELEM_F32;
+        cw = L.w; ch = L.h;
+      }
+      ProfScope ps(c, s, sp_n);
+      HIPCHK(c, launch_vif_stat(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
+                                (float)c->cfg.vif_enhn_gain_limit, c->vif_part[s]));
+    }
+  }
+  if ((feat & PQA_FEAT_ADM) && sp_n > 0) {
+    PlaneRun cr = rYs, cd = dYs;
+    Elem ce = c->elem;
+    int cw = w, ch = h;
+    for (int s = 0; s < 4; ++s) {
+      MutPlaneRun lr{nullptr, 0, 0}, ld{nullptr, 0, 0};
+      if (s < 3) {
+        Level& L = c->adm_lv[s + 1];
+        lr = MutPlaneRun{L.ref, L.pitch, L.frame_pitch};
+        ld = MutPlaneRun{L.dis, L.pitch, L.frame_pitch};
+      }
+      {
+        ProfScope ps(c, 7 + s, sp_n);
+        HIPCHK(c, launch_adm_scale(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
+                                   (float)c->cfg.adm_enhn_gain_limit, lr, ld, c->adm_part[s]));
+      }
+      if (s < 3) {
+        Level& L = c->adm_lv[s + 1];
+        cr = PlaneRun{L.ref, L.pitch, L.frame_pitch};
+        cd = PlaneRun{L.dis, L.pitch, L.frame_pitch};
+        ce = ELEM_F32;
+        cw = L.w; ch = L.h;
+      }
+    }
+  }
+  if (feat & PQA_FEAT_MOTION) {
+    const void* p0 = prev;
+    int64_t p0_pitch = prev_pitch_bytes;
+    if (!p0 && (c->halo_armed || (c->have_last && c->last_index == first - 1))) {
+      p0 = c->last_luma;
+      p0_pitch = c->last_luma_pitch;
+    }
+    if (p0 && p0_pitch % es) return fail(c, PQA_EINVAL, "halo pitch is not a multiple of the sample size");
+    ProfScope ps(c, 11, n);
+    HIPCHK(c, launch_motion(st, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h, c->inv_scale, c->motion_part));
+  }
+  int n_sse = 0, n_ssim = 0;
+  if (feat & PQA_FEAT_PSNR) {
+    n_sse = c->n_planes;
+    ProfScope ps(c, 12, n);
+    for (int p = 0; p < c->n_planes; ++p) {
+      const PlaneRun a{dis->plane[p], dis->row_pitch[p] / es, dis->frame_pitch[p] / es};
+      const PlaneRun b{ref->plane[p], ref->row_pitch[p] / es, ref->frame_pitch[p] / es};
+      HIPCHK(c, launch_sse(st, c->elem, a, b, n, c->pw[p], c->ph[p], c->sse_part[p]));
+    }
+  }
+  if (feat & PQA_FEAT_SSIM) {
+    n_ssim = c->n_planes;
+    ProfScope ps(c, 13, n);
+    for (int p = 0; p < c->n_planes; ++p) {
+      const PlaneRun a{dis->plane[p], dis->row_pitch[p] / es, dis->frame_pitch[p] / es};
+      const PlaneRun b{ref->plane[p], ref->row_pitch[p] / es, ref->frame_pitch[p] / es};
+      HIPCHK(c, launch_ssim(st, c->elem, a, b, n, c->pw[p], c->ph[p], (1 << c->cfg.bit_depth) - 1, c->ssim_part[p]));
+    }
+  }
+
+  FinalizeArgs fa{};
+  for (int s = 0; s < 4; ++s) {
+    fa.vif_part[s] = c->vif_part[s]; fa.vif_tiles[s] = c->vif_tiles[s];
+    fa.adm_part[s] = c->adm_part[s]; fa.adm_tiles[s] = c->adm_tiles[s]; fa.adm_area[s] = c->adm_area[s];
+  }
+  fa.motion_part = c->motion_part; fa.motion_tiles = c->motion_tiles_n;
+  fa.motion_norm = 1.0 / ((double)w * h);
+  for (int p = 0; p < 3; ++p) {
+    fa.sse_part[p] = c->sse_part[p];
+    fa.ssim_part[p] = c->ssim_part[p]; fa.ssim_tiles[p] = c->ssim_tiles_n[p]; fa.ssim_norm[p] = c->ssim_norm[p];
+  }
+  fa.records = c->records;
+  fa.record_stride = PQA_RECORD_DOUBLES;
+  fa.capacity = c->capacity;
+  {
+    ProfScope ps(c, 14, n);
+    if (k > 1) {
+      if (sp_n > 0 && (feat & (PQA_FEAT_VIF | PQA_FEAT_ADM))) {
+        FinalizeArgs f1 = fa;
+        f1.n_frames = sp_n;
+        f1.has_vif = !!(feat & PQA_FEAT_VIF); f1.has_adm = !!(feat & PQA_FEAT_ADM);
+        f1.slot_base = (int)((first + e0) % c->capacity); f1.slot_step = k;
+        HIPCHK(c, launch_finalize(st, f1));
+      }
+      FinalizeArgs f2 = fa;
+      f2.n_frames = n;
+      f2.has_motion = !!(feat & PQA_FEAT_MOTION); f2.n_sse_planes = n_sse; f2.n_ssim_planes = n_ssim;
+      f2.slot_base = (int)(first % c->capacity); f2.slot_step = 1;
+      HIPCHK(c, launch_finalize(st, f2));
+    } else {
+      fa.n_frames = n;
+      fa.has_vif = !!(feat & PQA_FEAT_VIF); fa.has_adm = !!(feat & PQA_FEAT_ADM);
+      fa.has_motion = !!(feat & PQA_FEAT_MOTION); fa.n_sse_planes = n_sse; fa.n_ssim_planes = n_ssim;
+      fa.slot_base = (int)(first % c->capacity); fa.slot_step = 1;
+      HIPCHK(c, launch_finalize(st, fa));
+    }
+  }
+  if (feat & PQA_FEAT_MOTION) {
+    // keep the last reference luma so the next batch continues the motion chain
+    const uint8_t* src = (const uint8_t*)ref->plane[0] + (int64_t)(n - 1) * ref->frame_pitch[0];
+    HIPCHK(c, hipMemcpy2DAsync(c->last_luma, c->last_luma_pitch, src, ref->row_pitch[0], (size_t)w * es, h,
+                               hipMemcpyDeviceToDevice, st));
+    c->have_last = true;
+    c->halo_armed = false;
+    c->last_index = first + n - 1;
+  }
+  return PQA_OK;
+}
+
+int ensure_staging(pqa_ctx* c) {
+  if (c->staging_ready) return PQA_OK;
+  size_t off = 0;
+  for (int side = 0; side < 2; ++side)
+    for (int p = 0; p < c->n_planes; ++p) {
+      c->slot_row_pitch[p] = round_up((int64_t)c->pw[p] * c->esize, 64);
+      c->plane_off[side][p] = off;
+      off += round_up(c->slot_row_pitch[p] * c->ph[p], 256);
+    }
+  c->slot_bytes = off;
+  for (int i = 0; i < 2; ++i) {
+    Half& H = c->half[i];
+    HIPCHK(c, hipHostMalloc((void**)&H.pinned, c->slot_bytes * c->B, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc((void**)&H.dev, c->slot_bytes * c->B));
+    HIPCHK(c, hipEventCreateWithFlags(&H.copied, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&H.computed, hipEventDisableTiming));
+  }
+  HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  c->staging_ready = true;
+  return PQA_OK;
+}
+
+int flush_pending(pqa_ctx* c) {
+  if (c->pending == 0) return PQA_OK;
+  Half& H = c->half[c->cur_half];
+  HIPCHK(c, hipEventRecord(H.copied, c->copy_stream));
+  H.copied_pending = true;
+  HIPCHK(c, hipStreamWaitEvent(c->stream, H.copied, 0));
+  pqa_device_clip r{}, d{};
+  for (int p = 0; p < c->n_planes; ++p) {
+    r.plane[p] = H.dev + c->plane_off[0][p];
+    d.plane[p] = H.dev + c->plane_off[1][p];
+    r.row_pitch[p] = d.row_pitch[p] = c->slot_row_pitch[p];
+    r.frame_pitch[p] = d.frame_pitch[p] = (int64_t)c->slot_bytes;
+  }
+  const int n = c->pending;
+  c->pending = 0;
+  int rc = process_batch(c, c->pending_first, n, &r, &d, nullptr, 0);
+  if (rc != PQA_OK) return rc;
+  HIPCHK(c, hipEventRecord(H.computed, c->stream));
+  H.computed_pending = true;
+  c->cur_half ^= 1;
+  return PQA_OK;
+}
+
+void copy_plane_rows(uint8_t* dst, int64_t dst_pitch, const uint8_t* src, int64_t src_pitch, size_t row_bytes, int h) {
+  if (dst_pitch == src_pitch) {
+    memcpy(dst, src, (size_t)dst_pitch * (h - 1) + row_bytes);
+    return;
+  }
+  for (int y = 0; y < h; ++y) memcpy(dst + (int64_t)y * dst_pitch, src + (int64_t)y * src_pitch, row_bytes);
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* pqa_version(void) { return "pqa_vmaf 0.1.0 (gfx950; libvmaf-float VIF/ADM/motion, FFmpeg psnr/ssim)"; }
+int pqa_record_doubles(void) { return PQA_RECORD_DOUBLES; }
+
+void pqa_config_init(pqa_config* cfg, uint32_t width, uint32_t height) {
+  if (!cfg) return;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = sizeof *cfg;
+  cfg->width = width; cfg->height = height;
+  cfg->bit_depth = 8;
+  cfg->n_planes = 1;
+  cfg->chroma_hshift = cfg->chroma_vshift = 1;
+  cfg->features = PQA_FEAT_VMAF;
+  cfg->max_batch = 8;
+  cfg->result_capacity = 16384;
+  cfg->n_subsample = 1;
+  cfg->vif_enhn_gain_limit = 100.0;
+  cfg->adm_enhn_gain_limit = 100.0;
+}
+
+int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, PQA_EINVAL, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(pqa_config)) return fail(nullptr, PQA_EINVAL, "pqa_config.struct_size mismatch");
+  if (cfg->width < 16 || cfg->height < 16 || cfg->width > 16384 || cfg->height > 16384)
+    return fail(nullptr, PQA_EINVAL, "unsupported frame size %ux%u (16..16384)", cfg->width, cfg->height);
+  if (cfg->bit_depth != 8 && cfg->bit_depth != 10 && cfg->bit_depth != 12)
+    return fail(nullptr, PQA_EINVAL, "unsupported bit depth %u (8, 10, 12)", cfg->bit_depth);
+  if (cfg->n_planes != 1 && cfg->n_planes != 3) return fail(nullptr, PQA_EINVAL, "n_planes must be 1 or 3");
+  if (cfg->chroma_hshift > 2 || cfg->chroma_vshift > 2) return fail(nullptr, PQA_EINVAL, "bad chroma shift");
+  if ((cfg->features & ~(uint32_t)PQA_FEAT_ALL) || cfg->features == 0)
+    return fail(nullptr, PQA_EINVAL, "bad feature mask 0x%x", cfg->features);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, PQA_EDEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, PQA_EINVAL, "device %d out of range (%d)", cfg->device, ndev);
+
+  pqa_ctx* c = new (std::nothrow) pqa_ctx();
+  if (!c) return fail(nullptr, PQA_ENOMEM, "out of host memory");
+  c->cfg = *cfg;
+  c->device = cfg->device;
+  c->B = cfg->max_batch ? (int)cfg->max_batch : 8;
+  if (c->B > 256) c->B = 256;
+  c->capacity = cfg->result_capacity ? (int)cfg->result_capacity : 16384;
+  if (c->capacity < c->B) c->capacity = c->B;
+  c->k_sub = cfg->n_subsample > 1 ? (int)cfg->n_subsample : 1;
+  if (c->cfg.vif_enhn_gain_limit <= 0) c->cfg.vif_enhn_gain_limit = 100.0;
+  if (c->cfg.adm_enhn_gain_limit <= 0) c->cfg.adm_enhn_gain_limit = 100.0;
+  c->elem = cfg->bit_depth > 8 ? ELEM_U16 : ELEM_U8;
+  c->esize = cfg->bit_depth > 8 ? 2 : 1;
+  c->inv_scale = 1.0f / (float)(1 << (cfg->bit_depth - 8));
+  c->n_planes = (int)cfg->n_planes;
+  c->pw[0] = (int)cfg->width; c->ph[0] = (int)cfg->height;
+  for (int p = 1; p < 3; ++p) {
+    c->pw[p] = (int)((cfg->width + (1u << cfg->chroma_hshift) - 1) >> cfg->chroma_hshift);
+    c->ph[p] = (int)((cfg->height + (1u << cfg->chroma_vshift) - 1) >> cfg->chroma_vshift);
+  }
+
+  auto bail = [&](int rc) {
+    g_create_error = c->err;
+    pqa_destroy(c);
+    return rc;
+  };
+#define CREATE_TRY(expr) do { int rc_ = (expr); if (rc_ != PQA_OK) return bail(rc_); } while (0)
+#define CREATE_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    fail(c, e_ == hipErrorOutOfMemory ? PQA_ENOMEM : PQA_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    return bail(e_ == hipErrorOutOfMemory ? PQA_ENOMEM : PQA_EDEVICE); } } while (0)
+
+  CREATE_HIP(hipSetDevice(c->device));
+  CREATE_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+
+  const int w = c->pw[0], h = c->ph[0], B = c->B;
+  // VIF pyramid (floor halving) and ADM approximation bands (ceil halving), f32, rows padded to 64 B
+  int vw = w, vh = h, aw = w, ah = h;
+  for (int s = 0; s < 4; ++s) {
+    if (s > 0) {
+      vw /= 2; vh /= 2;
+      aw = (aw + 1) / 2; ah = (ah + 1) / 2;
+      Level& V = c->vif_lv[s];
+      V.w = vw; V.h = vh; V.pitch = round_up(vw, 16); V.frame_pitch = V.pitch * vh;
+      Level& A = c->adm_lv[s];
+      A.w = aw; A.h = ah; A.pitch = round_up(aw, 16); A.frame_pitch = A.pitch * ah;
+      if (cfg->features & PQA_FEAT_VIF) {
+        CREATE_TRY(dev_alloc(c, &V.ref, (size_t)V.frame_pitch * B));
+        CREATE_TRY(dev_alloc(c, &V.dis, (size_t)V.frame_pitch * B));
+      }
+      if (cfg->features & PQA_FEAT_ADM) {
+        CREATE_TRY(dev_alloc(c, &A.ref, (size_t)A.frame_pitch * B));
+        CREATE_TRY(dev_alloc(c, &A.dis, (size_t)A.frame_pitch * B));
+      }
+    }
+    if (vw < 2 || vh < 2) { fail(c, PQA_EINVAL, "frame too small for 4 VIF scales"); return bail(PQA_EINVAL); }
+    c->vif_tiles[s] = vif_tiles_x(s, vw) * vif_tiles_y(vh);
+    const int bw = (aw + 1) / 2, bh = (ah + 1) / 2;  // band size produced at ADM scale s
+    c->adm_tiles[s] = adm_tiles_x(bw) * adm_tiles_y(bh);
+    const int left = (int)(bw * 0.1 - 0.5), top = (int)(bh * 0.1 - 0.5);
+    c->adm_area[s] = (float)((bh - 2 * top) * (bw - 2 * left));
+    if (cfg->features & PQA_FEAT_VIF) CREATE_TRY(dev_alloc(c, &c->vif_part[s], (size_t)c->vif_tiles[s] * 2 * B));
+    if (cfg->features & PQA_FEAT_ADM) CREATE_TRY(dev_alloc(c, &c->adm_part[s], (size_t)c->adm_tiles[s] * 6 * B));
+  }
+  c->motion_tiles_n = motion_tiles(w, h);
+  if (cfg->features & PQA_FEAT_MOTION) {
+    CREATE_TRY(dev_alloc(c, &c->motion_part, (size_t)c->motion_tiles_n * B));
+    c->last_luma_pitch = round_up((int64_t)w * c->esize, 64);
+    CREATE_TRY(dev_alloc(c, &c->last_luma, (size_t)c->last_luma_pitch * h));
+  }
+  for (int p = 0; p < c->n_planes; ++p) {
+    if (cfg->features & PQA_FEAT_PSNR) CREATE_TRY(dev_alloc(c, &c->sse_part[p], (size_t)kSseBlocksPerPlane * B));
+    if (cfg->features & PQA_FEAT_SSIM) {
+      c->ssim_tiles_n[p] = ssim_tiles(c->pw[p], c->ph[p]);
+      const int ww = (c->pw[p] >> 2) - 1, wh = (c->ph[p] >> 2) - 1;
+      c->ssim_norm[p] = (ww > 0 && wh > 0) ? 1.0 / ((double)ww * wh) : 0.0;
+      CREATE_TRY(dev_alloc(c, &c->ssim_part[p], (size_t)(c->ssim_tiles_n[p] ? c->ssim_tiles_n[p] : 1) * B));
+    }
+  }
+  CREATE_TRY(dev_alloc(c, &c->records, (size_t)c->capacity * PQA_RECORD_DOUBLES));
+  CREATE_HIP(hipMemsetAsync(c->records, 0, (size_t)c->capacity * PQA_RECORD_DOUBLES * sizeof(double), c->stream));
+  CREATE_HIP(hipStreamSynchronize(c->stream));
+#undef CREATE_TRY
+#undef CREATE_HIP
+  *out = c;
+  return PQA_OK;
+}
+
+void pqa_destroy(pqa_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+  prof_drain(c);
+  for (void* p : c->allocs) hipFree(p);
+  for (int i = 0; i < 2; ++i) {
+    Half& H = c->half[i];
+    if (H.pinned) hipHostFree(H.pinned);
+    if (H.dev) hipFree(H.dev);
+    if (H.copied) hipEventDestroy(H.copied);
+    if (H.computed) hipEventDestroy(H.computed);
+  }
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int pqa_set_stream(pqa_ctx* c, void* hip_stream) {
+  if (!c) return PQA_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return PQA_OK;
+}
+
+int pqa_submit_device(pqa_ctx* c, int64_t first_index, int32_t n_frames, const pqa_device_clip* ref,
+                      const pqa_device_clip* dis, const void* prev_ref_luma, int64_t prev_row_pitch) {
+  if (!c) return PQA_EINVAL;
+  if (!ref || !dis || n_frames < 0 || first_index < 0) return fail(c, PQA_EINVAL, "bad argument");
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = flush_pending(c);
+  if (rc != PQA_OK) return rc;
+  for (int done = 0; done < n_frames;) {
+    if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+    const int n = n_frames - done < c->B ? n_frames - done : c->B;
+    pqa_device_clip r = *ref, d = *dis;
+    for (int p = 0; p < c->n_planes; ++p) {
+      r.plane[p] = (const uint8_t*)ref->plane[p] + (int64_t)done * ref->frame_pitch[p];
+      d.plane[p] = (const uint8_t*)dis->plane[p] + (int64_t)done * dis->frame_pitch[p];
+    }
+    const void* prev = nullptr;
+    int64_t prev_pitch = 0;
+    if (done == 0) {
+      prev = prev_ref_luma;
+      prev_pitch = prev_row_pitch;
+    } else {
+      prev = (const uint8_t*)ref->plane[0] + (int64_t)(done - 1) * ref->frame_pitch[0];
+      prev_pitch = ref->row_pitch[0];
+    }
+    rc = process_batch(c, first_index + done, n, &r, &d, prev, prev_pitch);
+    if (rc != PQA_OK) return rc;
+    done += n;
+  }
+  return PQA_OK;
+}
+
+int pqa_submit(pqa_ctx* c, int64_t frame_index, const void* const ref_planes[3], const int64_t ref_strides[3],
+               const void* const dis_planes[3], const int64_t dis_strides[3]) {
+  if (!c) return PQA_EINVAL;
+  if (!ref_planes || !dis_planes || !ref_strides || !dis_strides || frame_index < 0)
+    return fail(c, PQA_EINVAL, "bad argument");
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_staging(c);
+  if (rc != PQA_OK) return rc;
+  if (c->pending > 0 && frame_index != c->pending_first + c->pending) {
+    rc = flush_pending(c);  // non-consecutive index starts a new run
+    if (rc != PQA_OK) return rc;
+  }
+  Half& H = c->half[c->cur_half];
+  if (c->pending == 0) {
+    c->pending_first = frame_index;
+    if (H.copied_pending) {  // pinned half still feeding an earlier upload?
+      HIPCHK(c, hipEventSynchronize(H.copied));
+      H.copied_pending = false;
+    }
+    if (H.computed_pending) {  // device half still read by an earlier batch?
+      HIPCHK(c, hipStreamWaitEvent(c->copy_stream, H.computed, 0));
+      H.computed_pending = false;
+    }
+  }
+  uint8_t* slot = H.pinned + (size_t)c->pending * c->slot_bytes;
+  for (int p = 0; p < c->n_planes; ++p) {
+    if (!ref_planes[p] || !dis_planes[p]) return fail(c, PQA_EINVAL, "plane %d pointer is null", p);
+    const size_t row_bytes = (size_t)c->pw[p] * c->esize;
+    if ((size_t)ref_strides[p] < row_bytes || (size_t)dis_strides[p] < row_bytes)
+      return fail(c, PQA_EINVAL, "plane %d stride smaller than a row", p);
+    copy_plane_rows(slot + c->plane_off[0][p], c->slot_row_pitch[p], (const uint8_t*)ref_planes[p], ref_strides[p],
+                    row_bytes, c->ph[p]);
+    copy_plane_rows(slot + c->plane_off[1][p], c->slot_row_pitch[p], (const uint8_t*)dis_planes[p], dis_strides[p],
+                    row_bytes, c->ph[p]);
+  }
+  HIPCHK(c, hipMemcpyAsync(H.dev + (size_t)c->pending * c->slot_bytes, slot, c->slot_bytes, hipMemcpyHostToDevice,
+                           c->copy_stream));
+  c->pending += 1;
+  if (c->pending == c->B) return flush_pending(c);
+  return PQA_OK;
+}
+
+int pqa_set_motion_halo(pqa_ctx* c, const void* prev_ref_luma_host, int64_t row_stride) {
+  if (!c) return PQA_EINVAL;
+  if (!(c->cfg.features & PQA_FEAT_MOTION)) return PQA_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = flush_pending(c);
+  if (rc != PQA_OK) return rc;
+  if (!prev_ref_luma_host) {
+    c->halo_armed = false;
+    c->have_last = false;
+    return PQA_OK;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy2D(c->last_luma, c->last_luma_pitch, prev_ref_luma_host, row_stride, (size_t)c->pw[0] * c->esize,
+                        c->ph[0], hipMemcpyHostToDevice));
+  c->halo_armed = true;
+  return PQA_OK;
+}
+
+int pqa_flush(pqa_ctx* c) {
+  if (!c) return PQA_EINVAL;
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  HIPCHK(c, hipSetDevice(c->device));
+  return flush_pending(c);
+}
+
+int pqa_sync(pqa_ctx* c) {
+  if (!c) return PQA_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = c->cancelled.load() ? PQA_OK : flush_pending(c);
+  if (rc != PQA_OK) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  return PQA_OK;
+}
+
+int pqa_collect(pqa_ctx* c, int64_t first_index, int32_t count, double* records) {
+  if (!c) return PQA_EINVAL;
+  if (count < 0 || first_index < 0 || (count > 0 && !records)) return fail(c, PQA_EINVAL, "bad argument");
+  if (count > c->capacity) return fail(c, PQA_ESTATE, "count %d exceeds result_capacity %d", count, c->capacity);
+  int rc = pqa_sync(c);
+  if (rc != PQA_OK) return rc;
+  const size_t rec_bytes = PQA_RECORD_DOUBLES * sizeof(double);
+  int64_t row = first_index % c->capacity;
+  int done = 0;
+  while (done < count) {
+    const int n = (int)((c->capacity - row) < (count - done) ? (c->capacity - row) : (count - done));
+    HIPCHK(c, hipMemcpy(records + (size_t)done * PQA_RECORD_DOUBLES, c->records + (size_t)row * PQA_RECORD_DOUBLES,
+                        n * rec_bytes, hipMemcpyDeviceToHost));
+    done += n;
+    row = 0;
+  }
+  return PQA_OK;
+}
+
+int pqa_cancel(pqa_ctx* c) {
+  if (!c) return PQA_EINVAL;
+  c->cancelled.store(1);
+  return PQA_OK;
+}
+
+int pqa_reset(pqa_ctx* c) {
+  if (!c) return PQA_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  c->cancelled.store(0);
+  c->pending = 0;
+  c->have_last = false;
+  c->halo_armed = false;
+  c->last_index = -1;
+  c->err.clear();
+  return PQA_OK;
+}
+
+const char* pqa_last_error(const pqa_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int pqa_profile_enable(pqa_ctx* c, int on) {
+  if (!c) return PQA_EINVAL;
+  prof_drain(c);
+  c->prof = on != 0;
+  if (on) {
+    memset(c->prof_ms, 0, sizeof c->prof_ms);
+    memset(c->prof_n, 0, sizeof c->prof_n);
+    memset(c->prof_frames, 0, sizeof c->prof_frames);
+  }
+  return PQA_OK;
+}
+
+int pqa_profile_read(pqa_ctx* c, int kernel_id, double* total_ms, uint64_t* launches, uint64_t* frames) {
+  if (!c || kernel_id < 0 || kernel_id >= PQA_PROF_KERNELS) return PQA_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  if (total_ms) *total_ms = c->prof_ms[kernel_id];
+  if (launches) *launches = c->prof_n[kernel_id];
+  if (frames) *frames = c->prof_frames[kernel_id];
+  return PQA_OK;
+}
+
+const char* pqa_profile_kernel_name(int kernel_id) {
+  return (kernel_id >= 0 && kernel_id < PQA_PROF_KERNELS) ? kProfNames[kernel_id] : "";
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Device-side helpers shared by the gfx950 feature kernels (wave64, LDS-staged stencils).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pqa {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 waves per workgroup everywhere
+
+// libvmaf border rule (vif_tools.c / adm_tools.c / convolution_internal.h): index -i -> i,
+// index n-1+i -> n-i (high edge repeats the edge sample).  Loop folds planes smaller than a radius.
+__device__ __forceinline__ int mirror(int i, int n) {
+  if (i < 0) i = -i;
+  else if (i >= n) i = 2 * n - i - 1;
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i;
+    else i = 2 * n - i - 1;
+  }
+  return i;
+}
+
+// luma sample -> float as libvmaf picture_copy does: v * inv_scale - 128 (inv_scale = 2^-(bpc-8)).
+template <typename T> struct PixIO;
+template <> struct PixIO<uint8_t> {
+  static __device__ __forceinline__ float load(const uint8_t* p, float) { return (float)(*p) - 128.0f; }
+  static __device__ __forceinline__ float raw(const uint8_t* p) { return (float)(*p); }
+};
+template <> struct PixIO<uint16_t> {
+  static __device__ __forceinline__ float load(const uint16_t* p, float inv_scale) {
+    return (float)(*p) * inv_scale - 128.0f;
+  }
+  static __device__ __forceinline__ float raw(const uint16_t* p) { return (float)(*p); }
+};
+template <> struct PixIO<float> {
+  static __device__ __forceinline__ float load(const float* p, float) { return *p; }
+  static __device__ __forceinline__ float raw(const float* p) { return *p; }
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give each XCD a
+// contiguous run of tile ids so tiles that share halo rows hit the same L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Deterministic block sum of NV doubles per thread (256 threads).  Result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [4*NV] */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = wave_sum(v[i]);
+    if (lane == 0) lds[wid * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (lds[i] + lds[NV + i]) + (lds[2 * NV + i] + lds[3 * NV + i]);
+  }
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32 (base 2)
+
+}  // namespace pqa

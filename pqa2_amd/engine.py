@@ -1,0 +1,134 @@
+"""FeatureEngine: thin Python owner of one pqa_ctx (one per GPU).
+
+Frames go in as numpy planes (host path, `submit`) or as a torch CUDA tensor that already holds a
+whole clip in HBM (`submit_resident`); per-frame feature records come back as a [n, 24] float64
+array.  All arithmetic happens in the HIP kernels behind the C ABI (include/pqa_vmaf.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class FeatureEngine:
+    def __init__(self, width: int, height: int, bit_depth: int = 8, n_planes: int = 1,
+                 chroma_shift=(1, 1), features: int = N.FEAT_VMAF, device: int = 0, max_batch: int = 8,
+                 result_capacity: int = 16384, n_subsample: int = 1,
+                 vif_enhn_gain_limit: float = 100.0, adm_enhn_gain_limit: float = 100.0):
+        self.lib = N.load()
+        cfg = N.PqaConfig()
+        self.lib.pqa_config_init(C.byref(cfg), width, height)
+        cfg.device = device
+        cfg.bit_depth = bit_depth
+        cfg.n_planes = n_planes
+        cfg.chroma_hshift, cfg.chroma_vshift = chroma_shift
+        cfg.features = features
+        cfg.max_batch = max_batch
+        cfg.result_capacity = result_capacity
+        cfg.n_subsample = n_subsample
+        cfg.vif_enhn_gain_limit = vif_enhn_gain_limit
+        cfg.adm_enhn_gain_limit = adm_enhn_gain_limit
+        self.cfg = cfg
+        self.width, self.height, self.bit_depth, self.n_planes = width, height, bit_depth, n_planes
+        self.dtype = np.uint8 if bit_depth <= 8 else np.dtype("<u2")
+        self._ctx = C.c_void_p()
+        rc = self.lib.pqa_create(C.byref(cfg), C.byref(self._ctx))
+        if rc != N.PQA_OK:
+            raise N.PqaError(rc, (self.lib.pqa_last_error(None) or b"").decode())
+
+    # -- lifetime ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self.lib.pqa_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc == N.PQA_OK:
+            return
+        msg = (self.lib.pqa_last_error(self._ctx) or b"").decode()
+        raise (N.PqaCancelled if rc == N.PQA_ECANCELLED else N.PqaError)(rc, msg)
+
+    # -- host path ---------------------------------------------------------------------------
+    def submit(self, index: int, ref_planes, dis_planes):
+        """ref_planes / dis_planes: sequences of 2-D numpy arrays (Y[,U,V]) of this engine's dtype."""
+        P, S = C.c_void_p * 3, C.c_int64 * 3
+        rp, rs, dp, ds = P(), S(), P(), S()
+        keep = []
+        for p in range(self.n_planes):
+            for arr, pp, ss in ((ref_planes[p], rp, rs), (dis_planes[p], dp, ds)):
+                a = np.asarray(arr)
+                if a.dtype != self.dtype or a.strides[1] != a.itemsize:
+                    a = np.ascontiguousarray(a, dtype=self.dtype)
+                keep.append(a)
+                pp[p] = a.ctypes.data
+                ss[p] = a.strides[0]
+        self._check(self.lib.pqa_submit(self._ctx, index, C.byref(rp), C.byref(rs), C.byref(dp), C.byref(ds)))
+
+    def set_motion_halo(self, prev_ref_luma: np.ndarray | None):
+        if prev_ref_luma is None:
+            self._check(self.lib.pqa_set_motion_halo(self._ctx, None, 0))
+            return
+        a = np.ascontiguousarray(prev_ref_luma, dtype=self.dtype)
+        self._check(self.lib.pqa_set_motion_halo(self._ctx, a.ctypes.data, a.strides[0]))
+
+    # -- device-resident path ------------------------------------------------------------------
+    def submit_resident(self, first_index: int, n_frames: int, ref_ptrs, dis_ptrs, row_pitch, frame_pitch,
+                        prev_ref_luma_ptr: int = 0, prev_row_pitch: int = 0):
+        """ref_ptrs/dis_ptrs: device addresses of frame 0's planes; pitches in bytes per plane."""
+        r, d = N.PqaDeviceClip(), N.PqaDeviceClip()
+        for p in range(self.n_planes):
+            r.plane[p], d.plane[p] = ref_ptrs[p], dis_ptrs[p]
+            r.row_pitch[p] = d.row_pitch[p] = row_pitch[p]
+            r.frame_pitch[p] = d.frame_pitch[p] = frame_pitch[p]
+        self._check(self.lib.pqa_submit_device(self._ctx, first_index, n_frames, C.byref(r), C.byref(d),
+                                               prev_ref_luma_ptr or None, prev_row_pitch))
+
+    # -- results -----------------------------------------------------------------------------
+    def collect(self, first_index: int, count: int) -> np.ndarray:
+        out = np.zeros((count, N.RECORD_DOUBLES), np.float64)
+        self._check(self.lib.pqa_collect(self._ctx, first_index, count, out.ctypes.data))
+        return out
+
+    def flush(self):
+        self._check(self.lib.pqa_flush(self._ctx))
+
+    def sync(self):
+        self._check(self.lib.pqa_sync(self._ctx))
+
+    def cancel(self):
+        self.lib.pqa_cancel(self._ctx)
+
+    def reset(self):
+        self._check(self.lib.pqa_reset(self._ctx))
+
+    # -- measurement ---------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.pqa_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self) -> dict:
+        out = {}
+        for k in range(N.PROF_KERNELS):
+            ms, n, fr = C.c_double(), C.c_uint64(), C.c_uint64()
+            self._check(self.lib.pqa_profile_read(self._ctx, k, C.byref(ms), C.byref(n), C.byref(fr)))
+            out[self.lib.pqa_profile_kernel_name(k).decode()] = {"ms": ms.value, "launches": n.value, "frames": fr.value}
+        return out
+
+
+def sse_from_records(rec: np.ndarray) -> np.ndarray:
+    """[n,3] uint64 SSE (Y,U,V) bit-cast out of the record slots."""
+    return np.ascontiguousarray(rec[:, N.REC_SSE:N.REC_SSE + 3]).view(np.uint64)

@@ -1,0 +1,224 @@
+"""Planar YUV containers the scoring path reads: YUV4MPEG2 (.y4m) and headerless raw (.yuv).
+
+The reference hands file paths to ffmpeg (app/vmaf_analyzer.py:411-419), which demuxes and
+decodes them.  This engine has no decoder of its own; it consumes what a decoder emits --
+planar Y, U, V at 8 or 10/12/16 bits (little-endian u16) -- from Y4M directly, from raw .yuv
+given the geometry, or from an `ffmpeg ... -f yuv4mpegpipe -` child when a system ffmpeg exists.
+"""
+from __future__ import annotations
+
+import io
+import os
+import re
+from dataclasses import dataclass
+
+import numpy as np
+
+_Y4M_CHROMA = {
+    # tag prefix -> (horizontal shift, vertical shift, bit depth, monochrome)
+    "420jpeg": (1, 1, 8, False), "420mpeg2": (1, 1, 8, False), "420paldv": (1, 1, 8, False),
+    "420": (1, 1, 8, False), "422": (1, 0, 8, False), "444": (0, 0, 8, False), "mono": (0, 0, 8, True),
+    "420p10": (1, 1, 10, False), "422p10": (1, 0, 10, False), "444p10": (0, 0, 10, False),
+    "420p12": (1, 1, 12, False), "422p12": (1, 0, 12, False), "444p12": (0, 0, 12, False),
+    "420p16": (1, 1, 16, False), "422p16": (1, 0, 16, False), "444p16": (0, 0, 16, False),
+    "mono10": (0, 0, 10, True), "mono12": (0, 0, 12, True), "mono16": (0, 0, 16, True),
+}
+
+
+@dataclass
+class VideoInfo:
+    width: int
+    height: int
+    bit_depth: int = 8
+    hshift: int = 1            # chroma subsampling shifts (4:2:0 -> 1,1)
+    vshift: int = 1
+    mono: bool = False
+    fps_num: int = 30
+    fps_den: int = 1
+    n_frames: int = 0
+    chroma_tag: str = "420jpeg"
+
+    @property
+    def dtype(self):
+        return np.uint8 if self.bit_depth <= 8 else np.dtype("<u2")
+
+    @property
+    def bytes_per_sample(self) -> int:
+        return 1 if self.bit_depth <= 8 else 2
+
+    @property
+    def chroma_w(self) -> int:
+        return 0 if self.mono else -(-self.width >> self.hshift)
+
+    @property
+    def chroma_h(self) -> int:
+        return 0 if self.mono else -(-self.height >> self.vshift)
+
+    @property
+    def plane_shapes(self):
+        s = [(self.height, self.width)]
+        if not self.mono:
+            s += [(self.chroma_h, self.chroma_w)] * 2
+        return s
+
+    @property
+    def frame_bytes(self) -> int:
+        return sum(h * w for h, w in self.plane_shapes) * self.bytes_per_sample
+
+    @property
+    def pix_fmt(self) -> str:
+        base = "gray" if self.mono else {(1, 1): "yuv420p", (1, 0): "yuv422p", (0, 0): "yuv444p"}[(self.hshift, self.vshift)]
+        if self.bit_depth > 8:
+            base += f"{self.bit_depth}le"
+        return base
+
+    @property
+    def fps(self) -> float:
+        return self.fps_num / self.fps_den if self.fps_den else 0.0
+
+
+class Y4MReader:
+    """Sequential/random-access reader of a YUV4MPEG2 file (memory-mapped, zero-copy planes)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        with open(path, "rb") as f:
+            head = f.readline(4096)
+        if not head.startswith(b"YUV4MPEG2"):
+            raise ValueError(f"not a YUV4MPEG2 file: {path}")
+        info = VideoInfo(0, 0)
+        for tok in head.decode("ascii", "replace").strip().split(" ")[1:]:
+            if not tok:
+                continue
+            k, v = tok[0], tok[1:]
+            if k == "W":
+                info.width = int(v)
+            elif k == "H":
+                info.height = int(v)
+            elif k == "F":
+                a, b = v.split(":")
+                info.fps_num, info.fps_den = int(a), int(b)
+            elif k == "C":
+                if v not in _Y4M_CHROMA:
+                    raise ValueError(f"unsupported Y4M chroma tag C{v}")
+                info.hshift, info.vshift, info.bit_depth, info.mono = _Y4M_CHROMA[v]
+                info.chroma_tag = v
+        if info.width <= 0 or info.height <= 0:
+            raise ValueError("Y4M header lacks W/H")
+        self.info = info
+        self._data_off = len(head)
+        self._mm = np.memmap(path, dtype=np.uint8, mode="r")
+        # frame markers: "FRAME" + optional params + "\n"; assume the common fixed 6-byte marker,
+        # fall back to a scan when a frame header carries parameters
+        fb = info.frame_bytes
+        size = self._mm.shape[0]
+        self._offsets = []
+        off = self._data_off
+        while off + 6 <= size:
+            if bytes(self._mm[off:off + 5]) != b"FRAME":
+                break
+            nl = off + 5
+            while nl < size and self._mm[nl] != 0x0A:
+                nl += 1
+            start = nl + 1
+            if start + fb > size:
+                break
+            self._offsets.append(start)
+            off = start + fb
+        info.n_frames = len(self._offsets)
+
+    def __len__(self):
+        return self.info.n_frames
+
+    def frame(self, i: int):
+        """Planes [Y, U, V] (or [Y]) of frame i as read-only arrays viewing the mapped file."""
+        info = self.info
+        off = self._offsets[i]
+        planes = []
+        for (h, w) in info.plane_shapes:
+            nbytes = h * w * info.bytes_per_sample
+            buf = self._mm[off:off + nbytes]
+            planes.append(buf.view(info.dtype).reshape(h, w))
+            off += nbytes
+        return planes
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self.frame(i)
+
+
+class RawYUVReader:
+    """Headerless planar .yuv; geometry from arguments or a `_WxH` / `_WxH_10bit` name hint."""
+
+    def __init__(self, path: str, width: int | None = None, height: int | None = None,
+                 bit_depth: int | None = None, fps: int = 30):
+        m = re.search(r"(\d{2,5})x(\d{2,5})", os.path.basename(path))
+        if (width is None or height is None) and not m:
+            raise ValueError(f"raw YUV needs a geometry (WxH in the file name or arguments): {path}")
+        width = width or int(m.group(1))
+        height = height or int(m.group(2))
+        if bit_depth is None:
+            mb = re.search(r"(\d{1,2})bit", os.path.basename(path))
+            bit_depth = int(mb.group(1)) if mb else 8
+        self.info = VideoInfo(width, height, bit_depth, 1, 1, False, fps, 1)
+        self._mm = np.memmap(path, dtype=np.uint8, mode="r")
+        self.info.n_frames = self._mm.shape[0] // self.info.frame_bytes
+
+    def __len__(self):
+        return self.info.n_frames
+
+    def frame(self, i: int):
+        info = self.info
+        off = i * info.frame_bytes
+        planes = []
+        for (h, w) in info.plane_shapes:
+            nbytes = h * w * info.bytes_per_sample
+            planes.append(self._mm[off:off + nbytes].view(info.dtype).reshape(h, w))
+            off += nbytes
+        return planes
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self.frame(i)
+
+
+def write_y4m(path: str, frames, info: VideoInfo) -> None:
+    """frames: iterable of [Y,U,V] plane lists matching `info`."""
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{info.width} H{info.height} F{info.fps_num}:{info.fps_den} Ip A1:1 C{info.chroma_tag}\n".encode())
+        for planes in frames:
+            f.write(b"FRAME\n")
+            for p in planes:
+                f.write(np.ascontiguousarray(p, dtype=info.dtype).tobytes())
+
+
+def open_video(path: str, **raw_kwargs):
+    """Reader for .y4m / .yuv; anything else is decoded by a system ffmpeg into a temp Y4M."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".y4m":
+        return Y4MReader(path)
+    if ext == ".yuv":
+        return RawYUVReader(path, **raw_kwargs)
+    with open(path, "rb") as f:
+        if f.read(9) == b"YUV4MPEG2":
+            return Y4MReader(path)
+    return _decode_with_ffmpeg(path)
+
+
+def _decode_with_ffmpeg(path: str):
+    """Compressed containers need a decoder; the reference relies on ffmpeg for that too
+    (app/vmaf_analyzer.py:411-419).  Only the *decode* is delegated -- never the metric filters."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("ffmpeg")
+    if not exe:
+        raise RuntimeError(
+            f"cannot decode {os.path.basename(path)}: no ffmpeg on PATH; supply .y4m or raw .yuv input")
+    tmp = tempfile.NamedTemporaryFile(suffix=".y4m", delete=False)
+    tmp.close()
+    subprocess.run([exe, "-hide_banner", "-loglevel", "error", "-y", "-i", path, "-f", "yuv4mpegpipe",
+                    "-strict", "-1", tmp.name], check=True)
+    rd = Y4MReader(tmp.name)
+    rd._tempfile = tmp.name
+    return rd

@@ -1,0 +1,185 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerances (written here because floating-point parity is a tolerance, not bit-equality):
+  * VIF / ADM num and den per scale: relative 5e-5 against the f64 oracle.  Rationale: libvmaf's own
+    f32 arithmetic (oracle f32) sits ~1e-6 from f64; the kernels use FMA, v_rcp_f32/v_log_f32
+    (1 ulp) and double cross-tile sums, which lands them at a few 1e-6.
+  * motion: absolute 2e-5 (values are O(1..20)).
+  * VMAF score from those features: |delta| <= 0.01 (north_star), asserted in test_gpu_engine.py.
+  * PSNR SSE: bit-exact integers.  SSIM: 1e-9 absolute (same float window expression, double sum).
+"""
+import numpy as np
+import pytest
+
+from pqa2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 5e-5
+MOTION_ATOL = 2e-5
+
+
+def _engine(w, h, **kw):
+    from pqa2_amd.engine import FeatureEngine
+    return FeatureEngine(w, h, **kw)
+
+
+def _oracle_clip(orc, refs, diss, bpc, **kw):
+    return orc.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc, **kw)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (176, 144), (321, 241), (130, 18), (16, 16), (640, 362)])
+def test_vmaf_features_8bit(oracle32, oracle64, w, h):
+    from pqa2_amd import _native as N
+    n = 4
+    refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+    exp64 = _oracle_clip(oracle64, refs, diss, 8)
+    exp32 = _oracle_clip(oracle32, refs, diss, 8)
+    with _engine(w, h, max_batch=3) as eng:   # batch 3 over 4 frames: exercises the partial batch + motion carry
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        rec = eng.collect(0, n)
+    got = rec[:, :17]
+    rel = np.abs(got[:, :16] - exp64[:, :16]) / np.maximum(np.abs(exp64[:, :16]), 1e-12)
+    rel32 = np.abs(exp32[:, :16] - exp64[:, :16]) / np.maximum(np.abs(exp64[:, :16]), 1e-12)
+    print(f"\n{w}x{h}: max rel err gpu-vs-f64 {rel.max():.3e} (oracle f32-vs-f64 {rel32.max():.3e}); "
+          f"motion abs err {np.abs(got[:, 16] - exp64[:, 16]).max():.3e}")
+    assert rel.max() < REL_TOL, f"feature mismatch at {np.unravel_index(rel.argmax(), rel.shape)}"
+    assert np.abs(got[:, 16] - exp64[:, 16]).max() < MOTION_ATOL
+    assert got[0, 16] == 0.0
+
+
+@pytest.mark.parametrize("bpc", [10, 12])
+def test_vmaf_features_hbd(oracle64, bpc):
+    w, h, n = 200, 120, 3
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
+    exp = _oracle_clip(oracle64, refs, diss, bpc)
+    with _engine(w, h, bit_depth=bpc) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        got = eng.collect(0, n)[:, :17]
+    rel = np.abs(got[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-12)
+    assert rel.max() < REL_TOL
+    assert np.abs(got[:, 16] - exp[:, 16]).max() < MOTION_ATOL
+
+
+def test_neg_model_gain_limits(oracle64):
+    """vmaf_*neg models set vif/adm enhn_gain_limit = 1.0 (models/vmaf_v0.6.1neg.json feature_opts_dicts)."""
+    w, h, n = 176, 144, 2
+    refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+    # make the distorted clip an *enhanced* (sharpened) version so the gain limit bites
+    diss = [[np.clip(2.0 * r[0].astype(np.float32) - d[0].astype(np.float32), 0, 255).astype(np.uint8)]
+            for r, d in zip(refs, diss)]
+    exp = _oracle_clip(oracle64, refs, diss, 8, vif_gain_limit=1.0, adm_gain_limit=1.0)
+    exp_default = _oracle_clip(oracle64, refs, diss, 8)
+    assert np.abs(exp - exp_default).max() > 1e-3  # the option matters on this input
+    with _engine(w, h, vif_enhn_gain_limit=1.0, adm_enhn_gain_limit=1.0) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        got = eng.collect(0, n)[:, :17]
+    rel = np.abs(got[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-12)
+    assert rel.max() < REL_TOL
+
+
+def test_identical_and_static_closed_forms():
+    """identical ref/dis -> every vif_scale = 1, adm = 1, SSE = 0, SSIM = 1; static clip -> motion = 0."""
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import sse_from_records
+    w, h = 192, 108
+    ref, _ = synth.make_pair(w, h, 0, 8, chroma=True)
+    with _engine(w, h, n_planes=3, features=N.FEAT_ALL) as eng:
+        for i in range(3):
+            eng.submit(i, ref, ref)
+        rec = eng.collect(0, 3)
+    np.testing.assert_allclose(rec[:, 0:4] / rec[:, 4:8], 1.0, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rec[:, 8:12] / rec[:, 12:16], 1.0, rtol=0, atol=1e-6)
+    assert np.all(rec[:, 16] == 0.0)
+    assert np.all(sse_from_records(rec) == 0)
+    np.testing.assert_allclose(rec[:, 17:20], 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("bpc,w,h", [(8, 322, 242), (8, 64, 48), (10, 200, 120), (8, 1920, 1080)])
+def test_psnr_sse_bit_exact_and_ssim(oracle32, bpc, w, h):
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import sse_from_records
+    n = 2
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=True)
+    with _engine(w, h, bit_depth=bpc, n_planes=3, features=N.FEAT_PSNR | N.FEAT_SSIM) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        rec = eng.collect(0, n)
+    sse = sse_from_records(rec)
+    for i in range(n):
+        for p in range(3):
+            assert int(sse[i, p]) == oracle32.sse_plane(diss[i][p], refs[i][p], bpc), (i, p)
+            exp = oracle32.ssim_plane(diss[i][p], refs[i][p], bpc)
+            assert abs(rec[i, 17 + p] - exp) < 1e-9, (i, p, rec[i, 17 + p], exp)
+
+
+def test_constant_offset_sse_closed_form():
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import sse_from_records
+    w, h, c = 130, 70, 7
+    ref = [np.full((h, w), 100, np.uint8)]
+    dis = [np.full((h, w), 100 + c, np.uint8)]
+    with _engine(w, h, features=N.FEAT_PSNR) as eng:
+        eng.submit(0, ref, dis)
+        rec = eng.collect(0, 1)
+    assert int(sse_from_records(rec)[0, 0]) == c * c * w * h
+
+
+def test_resident_path_matches_host_path_and_halo():
+    """Device-resident submit (torch tensor in HBM) == host submit, including the sharding halo."""
+    import torch
+    from pqa2_amd import _native as N
+    w, h, n = 256, 144, 6
+    refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+    with _engine(w, h, max_batch=4) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        host = eng.collect(0, n)
+    R = torch.from_numpy(np.stack([r[0] for r in refs])).cuda()
+    D = torch.from_numpy(np.stack([d[0] for d in diss])).cuda()
+    torch.cuda.synchronize()
+    with _engine(w, h, max_batch=4) as eng:
+        eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [w], [w * h])
+        dev = eng.collect(0, n)
+    assert np.array_equal(host, dev)  # fixed-order reductions: bit-identical
+    # second half as its own shard with a one-frame halo
+    with _engine(w, h, max_batch=4) as eng:
+        eng.submit_resident(3, 3, [R[3:].data_ptr()], [D[3:].data_ptr()], [w], [w * h],
+                            prev_ref_luma_ptr=R[2].data_ptr(), prev_row_pitch=w)
+        shard = eng.collect(3, 3)
+    assert np.array_equal(shard, host[3:])
+
+
+def test_n_subsample_and_cancel():
+    from pqa2_amd import _native as N
+    w, h, n = 128, 96, 5
+    refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+    with _engine(w, h) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        full = eng.collect(0, n)
+    with _engine(w, h, n_subsample=2, max_batch=4) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        sub = eng.collect(0, n)
+    assert np.array_equal(sub[::2, :16], full[::2, :16])      # spatial features on frames 0, 2, 4
+    assert np.array_equal(sub[:, 16], full[:, 16])            # motion on every frame
+    with _engine(w, h) as eng:
+        eng.submit(0, refs[0], diss[0])
+        eng.cancel()
+        with pytest.raises(N.PqaCancelled):
+            eng.submit(1, refs[1], diss[1])
+        eng.reset()
+        eng.submit(0, refs[0], diss[0])
+        assert np.array_equal(eng.collect(0, 1)[:, :16], full[:1, :16])
+
+
+def test_bad_config_is_rejected():
+    from pqa2_amd import _native as N
+    with pytest.raises(N.PqaError):
+        _engine(8, 8)
+    with pytest.raises(N.PqaError):
+        _engine(64, 64, bit_depth=9)
