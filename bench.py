@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- VMAF frames/s of the MI355X-native scoring path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one synthetic clip that is already resident in HBM:
+VIF + ADM + motion kernels for every frame -> per-frame records -> (N > 1: one RCCL all-gather of
+the records) -> SVM + pooling on the host of rank 0.  Weak scaling: every rank owns `--frames`
+consecutive frames of one long clip (rank r holds frames [r*F, (r+1)*F) plus the one-frame motion
+halo in front), so the job scores N*F frames per step.
+
+    python bench.py                      # N=1, 2160p vmaf_4k_v0.6.1, 300 frames
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed on the stream it runs on) and `cpu_baseline` (the CPU oracle = scalar port of the
+libvmaf float extractors, timed on a bounded sample of the same frames; N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (width, height, bit_depth, model, chroma+psnr+ssim)
+    "2160p": (3840, 2160, 8, "vmaf_4k_v0.6.1", False),
+    "1080p": (1920, 1080, 8, "vmaf_v0.6.1", False),
+    "2160p10": (3840, 2160, 10, "vmaf_v0.6.1neg", True),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="2160p", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=300, help="frames per rank")
+    ap.add_argument("--batch", type=int, default=8, help="frames per kernel launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=2)
+    ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pqa2_amd import _native as N
+    from pqa2_amd import model as M
+    from pqa2_amd import shard, synth_torch
+    from pqa2_amd.engine import FeatureEngine
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the scoring path has no CPU fallback)", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    w, h, bpc, model_name, side = WORKLOADS[args.workload]
+    F = args.frames
+    total = F * world
+    a = rank * F
+    feats = N.FEAT_VMAF | ((N.FEAT_PSNR | N.FEAT_SSIM) if side else 0)
+    n_planes = 3 if side else 1
+    model = M.load_model(model_name)
+
+    # ---- synthetic clip straight into HBM (this rank's chunk + one halo frame in front) ----------
+    halo = 1 if a > 0 else 0
+    clip = synth_torch.make_clip_cuda(w, h, F + halo, bpc, device=dev, chroma=side, t0=a - halo)
+    es = 1 if bpc <= 8 else 2
+    ref_t, dis_t = clip["ref"], clip["dis"]
+    ref_ptrs = [t[halo:].data_ptr() for t in ref_t]
+    dis_ptrs = [t[halo:].data_ptr() for t in dis_t]
+    row_pitch = [t.shape[2] * es for t in ref_t]
+    frame_pitch = [t.shape[1] * t.shape[2] * es for t in ref_t]
+    halo_ptr = ref_t[0][0].data_ptr() if halo else 0
+    torch.cuda.synchronize()
+
+    eng = FeatureEngine(w, h, bit_depth=bpc, n_planes=n_planes, features=feats, device=local_rank,
+                        max_batch=args.batch, result_capacity=max(F, 1024),
+                        vif_enhn_gain_limit=model.vif_enhn_gain_limit,
+                        adm_enhn_gain_limit=model.adm_enhn_gain_limit)
+    prefix = "integer_" if model.is_integer else ""
+    result = {}
+
+    def step():
+        eng.reset()
+        eng.submit_resident(a, F, ref_ptrs, dis_ptrs, row_pitch, frame_pitch, halo_ptr, row_pitch[0])
+        rec = eng.collect(a, F)
+        full = shard.gather_records(rec, total, world, rank, dev)
+        if rank == 0:
+            metrics = M.metrics_from_records(full, w, h, prefix)
+            scored = M.score_frames(model, metrics)
+            result["records"] = full
+            result["vmaf"] = scored["vmaf"]
+            result["pooled"] = M.pool(scored["vmaf"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_events:
+        eng.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read() if not args.no_events else {}
+    if not args.no_events:
+        eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        fps = total * args.steps / elapsed
+        b_alg = 2 * w * h * es  # every luma sample of the pair read once
+        out = {
+            "metric": "VMAF frames/sec (vif+adm+motion2 -> SVM), device-resident synthetic YUV pairs",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {w}x{h} {bpc}-bit, {model_name}, {F} frames/GPU"
+                                   f"{' + PSNR/SSIM all planes' if side else ''}",
+                       "frames_per_gpu": F, "frames_total": total, "batch": args.batch,
+                       "parallelism": f"frame-shard x{world}, 1-frame motion halo, 1 all-gather of records"},
+            "pooled_vmaf_mean": round(result["pooled"]["mean"], 6),
+        }
+        k = prof.get("vif_stat_s0")
+        if k and k["launches"]:
+            avg_ms = k["ms"] / k["launches"]
+            frames_per_launch = k["frames"] / k["launches"]
+            achieved = b_alg * frames_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = _traffic_from_profiles(args.workload)
+            out["roofline"] = {"bound": "hbm", "kernel": "vif_stat_kernel<u8,17,112> (VIF scale 0)",
+                               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 5),
+                               "traffic": traffic,
+                               "alg_bytes_per_launch": int(b_alg * frames_per_launch),
+                               "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"]}
+            tot = sum(v["ms"] for v in prof.values())
+            out["kernel_ms_per_frame"] = {name: round(v["ms"] / max(1, v["frames"]), 5)
+                                          for name, v in prof.items() if v["launches"]}
+            out["kernel_time_share_of_step"] = round(tot / (1e3 * elapsed), 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, args.cpu_sample_frames,
+                                                result["records"], model, prefix)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _traffic_from_profiles(workload: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes, if any."""
+    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(p) as f:
+            d = json.load(f)
+        return d.get(workload, {}).get("vif_stat_s0_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, gpu_records, model, prefix):
+    """Time the CPU oracle (scalar C port of the libvmaf float extractors, 1 thread) on the first
+    `n_sample` frames of the very same clip, and report how far the GPU records are from it."""
+    from oracle.oracle import Oracle
+    from pqa2_amd import model as M
+    orc = Oracle("f32")
+    refs = [ref_t[0][halo + i].cpu().numpy() for i in range(n_sample)]
+    diss = [dis_t[0][halo + i].cpu().numpy() for i in range(n_sample)]
+    if bpc > 8:
+        refs = [r.view(np.uint16) for r in refs]
+        diss = [d.view(np.uint16) for d in diss]
+    t0 = time.perf_counter()
+    exp = orc.clip_features(refs, diss, bpc, vif_gain_limit=model.vif_enhn_gain_limit,
+                            adm_gain_limit=model.adm_enhn_gain_limit)
+    dt = time.perf_counter() - t0
+    got = gpu_records[:n_sample, :17]
+    rel = np.abs(got[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-12)
+    rec = np.zeros((n_sample, 24))
+    rec[:, :17] = exp
+    v_cpu = M.score_frames(model, M.metrics_from_records(rec, w, h, prefix))["vmaf"]
+    v_gpu = M.score_frames(model, M.metrics_from_records(gpu_records[:n_sample], w, h, prefix))["vmaf"]
+    return {"value": round(n_sample / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_sample} frames of the same clip, oracle/vmaf_oracle.c f32 (VIF+ADM+motion), "
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores; ffmpeg/libvmaf not present on this box",
+            "gpu_vs_oracle_max_rel_feature_err": float(rel.max()),
+            "gpu_vs_oracle_max_abs_vmaf_err": float(np.abs(v_cpu - v_gpu).max())}
+
+
+if __name__ == "__main__":
+    main()
