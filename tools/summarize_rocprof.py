@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/...) into the small files kept under profiles/.
+
+usage: summarize_rocprof.py --stats DIR --fetch DIR --write DIR --frames-per-launch 8 --tag r01_2160p
+Writes profiles/<tag>_kernel_stats.csv (the --stats summary, pqa kernels first) and
+profiles/<tag>_pmc.json (per-kernel FETCH_SIZE / WRITE_SIZE per launch, raw KB and corrected bytes:
+MI355X_MICROARCH.md 'HBM': FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950,
+WRITE_SIZE is exact; other widths are uncalibrated, which is stated in the file)."""
+import argparse, collections, csv, glob, json, os
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--stats"); ap.add_argument("--fetch"); ap.add_argument("--write")
+ap.add_argument("--tag", required=True); ap.add_argument("--frames-per-launch", type=float, default=8)
+ap.add_argument("--workload", default="2160p")
+a = ap.parse_args()
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(root, exist_ok=True)
+
+def short(name):
+    n = name.replace("pqa::(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0] if "pqa" in name or "_kernel" in n[:40] else n[:80]
+
+if a.stats:
+    f = glob.glob(os.path.join(a.stats, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    ours = [r for r in rows if "pqa::" in r["Name"]]
+    rest = [r for r in rows if "pqa::" not in r["Name"]]
+    tot_ours = sum(float(r["TotalDurationNs"]) for r in ours)
+    with open(os.path.join(root, f"{a.tag}_kernel_stats.csv"), "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats summary; pqa kernels (the scoring path) first, then the top\n")
+        o.write("# torch kernels of the synthetic-clip generator (outside the timed region).\n")
+        o.write("Name,Calls,TotalDurationNs,AverageNs,PercentOfPqaTime,MinNs,MaxNs\n")
+        for r in ours:
+            o.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.1f},"
+                    f"{100*float(r['TotalDurationNs'])/tot_ours:.2f},{r['MinNs']},{r['MaxNs']}\n")
+        for r in rest[:8]:
+            o.write(f"\"[generator] {short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.1f},,{r['MinNs']},{r['MaxNs']}\n")
+
+pmc = collections.defaultdict(dict)
+for kind, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
+    if not d:
+        continue
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if "pqa::" not in r["Kernel_Name"] or r["Counter_Name"] != kind:
+            continue
+        k = short(r["Kernel_Name"]); agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+    for k, (n, v) in agg.items():
+        pmc[k][kind + "_KB_per_launch"] = v / n
+        pmc[k]["launches_" + kind] = n
+for k, d in pmc.items():
+    fb = d.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024
+    wb = d.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
+    d["hbm_bytes_per_launch_corrected"] = 2 * fb + wb   # gfx950: FETCH_SIZE x2 (wide-read calibration), WRITE_SIZE exact
+    d["hbm_bytes_per_frame_corrected"] = (2 * fb + wb) / a.frames_per_launch
+if pmc:
+    out = {"workload": a.workload, "frames_per_launch": a.frames_per_launch,
+           "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only; bytes = 2*FETCH_SIZE*1024 + "
+                   "WRITE_SIZE*1024 per MI355X_MICROARCH.md HBM section.  The x2 is calibrated for 16-B/lane streams; these "
+                   "kernels read 1-4 B/lane row segments, so treat the absolute as +-2x and the ratios as exact.",
+           "kernels": pmc}
+    json.dump(out, open(os.path.join(root, f"{a.tag}_pmc.json"), "w"), indent=1)
+    k0 = next((k for k in pmc if k.startswith("vif_stat_kernel<unsigned char, 17")), None)
+    tj = os.path.join(root, "hbm_traffic.json")
+    cur = json.load(open(tj)) if os.path.exists(tj) else {}
+    if k0:
+        cur[a.workload] = {"vif_stat_s0_bytes_per_launch": int(pmc[k0]["hbm_bytes_per_launch_corrected"]),
+                           "frames_per_launch": a.frames_per_launch, "source": f"profiles/{a.tag}_pmc.json"}
+        json.dump(cur, open(tj, "w"), indent=1)
+print("ok")
