@@ -1,0 +1,76 @@
+"""Command-line / torchrun entry of the scoring path:
+
+    python -m pqa2_amd.score REF DIS --model vmaf_v0.6.1 --json out.json [--psnr-log p.txt --ssim-log s.txt]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           -m pqa2_amd.score REF DIS --json out.json          # frame-sharded, one process per GPU
+
+Progress goes to stderr as `frame= N` lines -- the same shape the reference parses from its ffmpeg
+child (app/vmaf_analyzer.py:475-492), so VMAFAnalyzer drives a multi-GPU job exactly the way the
+reference drives ffmpeg."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="pqa2_amd.score")
+    ap.add_argument("reference")
+    ap.add_argument("distorted")
+    ap.add_argument("--model", default="vmaf_v0.6.1")
+    ap.add_argument("--json", required=True)
+    ap.add_argument("--psnr-log")
+    ap.add_argument("--ssim-log")
+    ap.add_argument("--n-subsample", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args(argv)
+
+    from . import report
+    from .pipeline import score_files
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gather_device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        gather_device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=gather_device)
+    last = [0.0]
+
+    def progress(done, total):
+        now = time.time()
+        if rank == 0 and (now - last[0] > 0.25 or done == total):
+            last[0] = now
+            print(f"frame= {done * world} fps=0 q=0.0 size=N/A", file=sys.stderr, flush=True)
+
+    try:
+        res = score_files(a.reference, a.distorted, a.model, psnr=bool(a.psnr_log), ssim=bool(a.ssim_log),
+                          n_subsample=a.n_subsample, device=local_rank, rank=rank, world_size=world,
+                          gather_device=gather_device, max_batch=a.batch, progress=progress)
+    except Exception as e:  # one line on stderr, non-zero exit: what the caller's returncode check expects
+        print(f"pqa2_amd.score: error: {e}", file=sys.stderr, flush=True)
+        return 1
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+    if rank == 0:
+        log = report.build_vmaf_log(res["metrics"], res["fps"], res["frame_indices"], {"model": res["model_name"]})
+        report.write_vmaf_json(a.json, log)
+        if a.psnr_log and res["psnr_lines"] is not None:
+            with open(a.psnr_log, "w") as f:
+                f.write("\n".join(res["psnr_lines"]) + "\n")
+        if a.ssim_log and res["ssim_lines"] is not None:
+            with open(a.ssim_log, "w") as f:
+                f.write("\n".join(res["ssim_lines"]) + "\n")
+        print(f"VMAF score: {log['pooled_metrics']['vmaf']['mean']:.6f}", file=sys.stderr, flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

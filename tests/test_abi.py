@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/pqa_vmaf.h declares.
+No compute calls here: without a device pqa_create must fail loudly (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pqa_vmaf.h")).read()
+    return sorted(set(re.findall(r"PQA_API\s+[\w\s\*]+?\b(pqa_\w+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from pqa2_amd import _native as N
+    assert _declared() == sorted(N.EXPORTS)
+    src = open(os.path.join(ROOT, "include", "pqa_vmaf.h")).read()
+    assert int(re.search(r"PQA_RECORD_DOUBLES\s*=\s*(\d+)", src).group(1)) == N.RECORD_DOUBLES
+    for name, val in (("PQA_REC_MOTION", N.REC_MOTION), ("PQA_REC_SSIM", N.REC_SSIM), ("PQA_REC_SSE", N.REC_SSE)):
+        assert int(re.search(name + r"\s*=\s*(\d+)", src).group(1)) == val
+
+
+def test_library_exports_every_declared_symbol():
+    from pqa2_amd import _native as N
+    if not os.path.exists(N.LIB_PATH):
+        N.build()
+    lib = N.load()
+    for sym in _declared():
+        assert hasattr(lib, sym), sym
+    assert b"gfx950" in lib.pqa_version()
+    assert lib.pqa_record_doubles() == 24
+    cfg = N.PqaConfig()
+    lib.pqa_config_init(C.byref(cfg), 1920, 1080)
+    assert (cfg.struct_size, cfg.width, cfg.height, cfg.bit_depth, cfg.features) == (C.sizeof(N.PqaConfig), 1920, 1080, 8, N.FEAT_VMAF)
+    assert cfg.vif_enhn_gain_limit == 100.0 and cfg.adm_enhn_gain_limit == 100.0
+    assert lib.pqa_profile_kernel_name(0) == b"vif_stat_s0"
+
+
+def test_create_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import FeatureEngine
+    with pytest.raises(N.PqaError) as e:
+        FeatureEngine(64, 64)
+    assert e.value.code == N.PQA_EDEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_bad_arguments_do_not_crash():
+    from pqa2_amd import _native as N
+    lib = N.load()
+    assert lib.pqa_create(None, None) == N.PQA_EINVAL
+    cfg = N.PqaConfig()
+    lib.pqa_config_init(C.byref(cfg), 8, 8)
+    ctx = C.c_void_p()
+    assert lib.pqa_create(C.byref(cfg), C.byref(ctx)) == N.PQA_EINVAL and b"frame size" in lib.pqa_last_error(None)
+    lib.pqa_destroy(None)
+    assert lib.pqa_cancel(None) == N.PQA_EINVAL

@@ -1,0 +1,119 @@
+"""GPU end-to-end: VMAFAnalyzer.analyze_videos through the real HIP engine; score parity with the
+oracle within north_star's tolerance (|dVMAF| <= 0.01); full-size (1080p / 2160p) checks through
+size-independent properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pqa2_amd import model as M
+from pqa2_amd import synth, yuvio
+
+pytestmark = pytest.mark.gpu
+VMAF_TOL = 0.01   # BASELINE.json north_star: per-frame and pooled scores within +-0.01 VMAF
+
+
+def _pair(tmp_path, w, h, n, bpc=8):
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=True)
+    info = synth.clip_info(w, h, bpc)
+    rp, dp = str(tmp_path / "ref.y4m"), str(tmp_path / "dist.y4m")
+    yuvio.write_y4m(rp, refs, info)
+    yuvio.write_y4m(dp, diss, info)
+    return rp, dp, refs, diss
+
+
+@pytest.mark.parametrize("w,h,bpc,model", [(352, 288, 8, "vmaf_v0.6.1"), (321, 241, 8, "vmaf_4k_v0.6.1"),
+                                            (320, 180, 10, "vmaf_v0.6.1neg")])
+def test_analyzer_scores_match_oracle(tmp_path, oracle32, w, h, bpc, model):
+    from pqa2_amd.vmaf_analyzer import VMAFAnalyzer
+    n = 5
+    rp, dp, refs, diss = _pair(tmp_path, w, h, n, bpc)
+    a = VMAFAnalyzer()
+    a.set_output_directory(str(tmp_path))
+    a.set_test_name("gpu")
+    errors = []
+    a.error_occurred.connect(errors.append)
+    res = a.analyze_videos(rp, dp, model)
+    assert errors == [] and res is not None
+    mdl = M.load_model(model)
+    rec = np.zeros((n, 24))
+    rec[:, :17] = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc,
+                                         vif_gain_limit=mdl.vif_enhn_gain_limit, adm_gain_limit=mdl.adm_enhn_gain_limit)
+    want = M.score_frames(mdl, M.metrics_from_records(rec, w, h, "integer_"))
+    got = res["raw_results"]["frames"]
+    dv = max(abs(got[i]["metrics"]["vmaf"] - want["vmaf"][i]) for i in range(n))
+    assert dv <= VMAF_TOL, dv
+    assert abs(res["vmaf_score"] - float(np.mean(want["vmaf"]))) <= VMAF_TOL
+    for k in ("integer_adm2", "integer_motion2", "integer_vif_scale0", "integer_vif_scale1", "integer_vif_scale2", "integer_vif_scale3"):
+        d = max(abs(got[i]["metrics"][k] - want[k][i]) for i in range(n))
+        assert d < 2e-5, (k, d)
+    # PSNR stats: exact integer SSE -> identical 2-decimal text to the oracle-derived line
+    from pqa2_amd import report
+    sse = np.array([[oracle32.sse_plane(diss[i][p], refs[i][p], bpc) for p in range(3)] for i in range(n)], np.uint64)
+    sizes = [(w, h), ((w + 1) // 2, (h + 1) // 2), ((w + 1) // 2, (h + 1) // 2)]
+    assert open(res["psnr_log"]).read().split("\n")[:-1] == report.psnr_stats_lines(sse, sizes, bpc)
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+def test_full_size_properties(w, h):
+    """BASELINE sizes, checked through properties that need no oracle pass:
+    identical -> vif/adm == 1, SSE == 0; static -> motion == 0; +c offset -> SSE == c^2*W*H and a
+    bounded, monotone VMAF drop; host path == device-resident path bit for bit."""
+    import torch
+    from pqa2_amd import _native as N
+    from pqa2_amd import synth_torch
+    from pqa2_amd.engine import FeatureEngine, sse_from_records
+    clip = synth_torch.make_clip_cuda(w, h, 3, 8, device="cuda")
+    R, D = clip["ref"][0], clip["dis"][0]
+    torch.cuda.synchronize()
+    with FeatureEngine(w, h, features=N.FEAT_VMAF | N.FEAT_PSNR | N.FEAT_SSIM, max_batch=2) as eng:
+        eng.submit_resident(0, 3, [R.data_ptr()], [R.data_ptr()], [w], [w * h])          # identical
+        ident = eng.collect(0, 3)
+        eng.reset()
+        eng.submit_resident(0, 3, [R.data_ptr()], [D.data_ptr()], [w], [w * h])          # real pair
+        pair = eng.collect(0, 3)
+        Rs = R[:1].expand(3, h, w).contiguous()
+        eng.reset()
+        eng.submit_resident(0, 3, [Rs.data_ptr()], [Rs.data_ptr()], [w], [w * h])        # static
+        static = eng.collect(0, 3)
+        c = 3
+        Ro = (R.to(torch.int16).clamp(0, 255 - c) + c).to(torch.uint8)
+        Rc = R.to(torch.int16).clamp(0, 255 - c).to(torch.uint8)
+        eng.reset()
+        eng.submit_resident(0, 3, [Rc.data_ptr()], [Ro.data_ptr()], [w], [w * h])        # constant offset
+        off = eng.collect(0, 3)
+    # vif: flat regions take the low-variance branch (num = 1 - sigma2^2 * 4/255^2, den = 1), so identical
+    # frames give 1 - O(1e-6), in libvmaf too; adm is exactly num == den
+    np.testing.assert_allclose(ident[:, 0:4] / ident[:, 4:8], 1.0, atol=2e-5)
+    assert np.all(ident[:, 0:4] <= ident[:, 4:8])
+    np.testing.assert_allclose(ident[:, 8:12] / ident[:, 12:16], 1.0, atol=1e-6)
+    assert np.all(sse_from_records(ident)[:, 0] == 0) and np.allclose(ident[:, 17], 1.0)
+    assert np.all(static[:, 16] == 0.0) and pair[0, 16] == 0.0 and np.all(pair[1:, 16] > 0)
+    assert np.all(sse_from_records(off)[:, 0] == c * c * w * h)
+    # host path over the same bytes is bit-identical (fixed-order reductions)
+    with FeatureEngine(w, h, features=N.FEAT_VMAF | N.FEAT_PSNR | N.FEAT_SSIM, max_batch=3) as eng:
+        Rh, Dh = R.cpu().numpy(), D.cpu().numpy()
+        for i in range(3):
+            eng.submit(i, [Rh[i]], [Dh[i]])
+        host = eng.collect(0, 3)
+    assert np.array_equal(host.view(np.uint64), pair.view(np.uint64))
+    mdl = M.load_model("vmaf_v0.6.1")
+    v_pair = M.score_frames(mdl, M.metrics_from_records(pair, w, h, "integer_"))["vmaf"]
+    v_id = M.score_frames(mdl, M.metrics_from_records(ident, w, h, "integer_"))["vmaf"]
+    assert np.all(v_pair < v_id) and np.all(v_pair > 20)
+
+
+def test_one_oracle_frame_at_1080p(oracle32):
+    """One full-size frame against the oracle (about 1 s of CPU)."""
+    from pqa2_amd.engine import FeatureEngine
+    w, h = 1920, 1080
+    refs, diss = synth.make_clip(w, h, 2, 8, chroma=False)
+    exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], 8)
+    with FeatureEngine(w, h) as eng:
+        for i in range(2):
+            eng.submit(i, refs[i], diss[i])
+        got = eng.collect(0, 2)[:, :17]
+    rel = np.abs(got[:, :16] - exp[:, :16]) / np.abs(exp[:, :16])
+    # motion: the f32 oracle sums 2M pixels in float like libvmaf (~1e-6 relative); the kernel sums in double
+    assert rel.max() < 5e-5 and abs(got[1, 16] - exp[1, 16]) < 5e-6 * exp[1, 16] + 2e-5

@@ -1,0 +1,179 @@
+"""Host-side logic on CPU: model files, SVM, pooling, libvmaf-format JSON, FFmpeg stats files, Y4M I/O,
+and the VMAFAnalyzer boundary (signals, files, result dict, errors, cancel) -- with the oracle-backed
+stand-in engine injected where the HIP engine would be."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle.oracle import svr_predict_py
+from pqa2_amd import model as M
+from pqa2_amd import report, synth, yuvio
+from tests.fake_engine import OracleEngine
+
+
+def _write_pair(tmp_path, w=96, h=64, n=4, bpc=8):
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=True)
+    info = synth.clip_info(w, h, bpc)
+    rp, dp = str(tmp_path / "ref.y4m"), str(tmp_path / "dist.y4m")
+    yuvio.write_y4m(rp, refs, info)
+    yuvio.write_y4m(dp, diss, info)
+    return rp, dp, refs, diss
+
+
+def test_models_load_unchanged_and_predict_matches_loop_restatement():
+    rng = np.random.default_rng(1)
+    for name in ("vmaf_v0.6.1", "vmaf_4k_v0.6.1", "vmaf_float_v0.6.1", "vmaf_v0.6.1neg"):
+        m = M.load_model(name)
+        with open(m.path) as f:
+            md = json.load(f)["model_dict"]
+        X = np.column_stack([rng.uniform(0.5, 1, 5), rng.uniform(0, 10, 5)] + [rng.uniform(0.2, 1, 5) for _ in range(4)])
+        got = m.main.predict(X)
+        want = [svr_predict_py(md, list(x)) for x in X]
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    assert abs(M.load_model("vmaf_v0.6.1").main.predict(np.array([[1, 0, 1, 1, 1, 1.0]]))[0] - 97.428043) < 1e-6
+    neg = M.load_model("vmaf_v0.6.1neg")
+    assert neg.vif_enhn_gain_limit == 1.0 and neg.adm_enhn_gain_limit == 1.0
+    assert M.load_model("vmaf_v0.6.1").main.metric_keys[0] == "integer_adm2"
+    assert M.load_model("vmaf_float_v0.6.1").main.metric_keys[0] == "adm2"
+    b = M.load_model("vmaf_b_v0.6.3")
+    assert len(b.models) == 21
+    with pytest.raises(FileNotFoundError):
+        M.load_model("vmaf_v9")
+
+
+def test_pooling_and_log_schema(tmp_path):
+    v = np.array([80.0, 90.0, 100.0])
+    p = M.pool(v)
+    assert p["mean"] == 90.0 and p["min"] == 80.0 and p["max"] == 100.0
+    assert abs(p["harmonic_mean"] - (1.0 / np.mean(1.0 / (v + 1.0)) - 1.0)) < 1e-12
+    metrics = {"integer_motion2": np.array([0.0, 1.5, 1.5]), "vmaf": v}
+    log = report.build_vmaf_log(metrics, 123.456, None, {"model": "vmaf_v0.6.1"})
+    path = str(tmp_path / "x_vmaf.json")
+    report.write_vmaf_json(path, log)
+    text = open(path).read()
+    assert '"vmaf": 80.000000' in text and '"frameNum": 0' in text          # libvmaf's %.6f form
+    back = json.load(open(path))
+    assert list(back.keys())[:1] == ["version"] and back["frames"][1]["metrics"]["integer_motion2"] == 1.5
+    assert back["pooled_metrics"]["vmaf"]["mean"] == 90.0 and back["aggregate_metrics"] == {}
+
+
+def test_ffmpeg_stats_file_lines():
+    sse = np.array([[1000, 10, 0]], np.uint64)
+    sizes = [(8, 8), (4, 4), (4, 4)]
+    line = report.psnr_stats_lines(sse, sizes, 8)[0]
+    mse_y, mse_u = 1000 / 64, 10 / 16
+    mse_avg = (mse_y * 64 + mse_u * 16) / 96
+    assert line.startswith(f"n:1 mse_avg:{mse_avg:.2f} mse_y:{mse_y:.2f} mse_u:{mse_u:.2f} mse_v:0.00 ")
+    assert "psnr_v:inf" in line and f"psnr_y:{10 * np.log10(255 ** 2 / mse_y):.2f}" in line
+    s = report.ssim_stats_lines(np.array([[0.9, 0.8, 1.0]]), sizes)[0]
+    allv = (0.9 * 64 + 0.8 * 16 + 1.0 * 16) / 96
+    assert s == f"n:1 Y:0.900000 U:0.800000 V:1.000000 All:{allv:f} ({-10 * np.log10(1 - allv):f})"
+
+
+def test_y4m_roundtrip_and_raw(tmp_path):
+    for bpc in (8, 10):
+        rp, dp, refs, diss = _write_pair(tmp_path, 50, 34, 3, bpc)
+        rd = yuvio.open_video(rp)
+        assert len(rd) == 3 and (rd.info.width, rd.info.height, rd.info.bit_depth) == (50, 34, bpc)
+        for i in range(3):
+            for p in range(3):
+                np.testing.assert_array_equal(rd.frame(i)[p], refs[i][p])
+    raw = tmp_path / "clip_50x34.yuv"
+    with open(raw, "wb") as f:
+        for fr in refs[:2]:
+            for p in fr:
+                f.write(np.ascontiguousarray(p).tobytes())
+    rr = yuvio.open_video(str(raw), bit_depth=10)
+    assert len(rr) == 2
+    np.testing.assert_array_equal(rr.frame(1)[0], refs[1][0])
+
+
+def _analyzer(tmp_path):
+    from pqa2_amd.vmaf_analyzer import VMAFAnalyzer
+    a = VMAFAnalyzer()
+    a._engine_factory = OracleEngine
+    a.set_output_directory(str(tmp_path / "out"))
+    os.makedirs(tmp_path / "out", exist_ok=True)
+    a.set_test_name("T")
+    ev = {"progress": [], "status": [], "errors": [], "complete": []}
+    a.analysis_progress.connect(ev["progress"].append)
+    a.status_update.connect(ev["status"].append)
+    a.error_occurred.connect(ev["errors"].append)
+    a.analysis_complete.connect(ev["complete"].append)
+    return a, ev
+
+
+def test_analyzer_boundary_contract(tmp_path, oracle32):
+    rp, dp, refs, diss = _write_pair(tmp_path)
+    a, ev = _analyzer(tmp_path)
+    res = a.analyze_videos(rp, dp, "vmaf_v0.6.1", duration=5)
+    assert ev["errors"] == [] and res is not None and ev["complete"] == [res]
+    # result dict keys = the reference's final dict (app/vmaf_analyzer.py:919-932)
+    assert set(res) == {"distorted_video", "height", "json_path", "model", "psnr_log", "psnr_score", "raw_results",
+                        "reference_video", "ssim_log", "ssim_score", "vmaf_score", "width"}
+    assert (res["width"], res["height"]) == (96, 64)
+    assert res["reference_video"] == "ref.y4m" and res["distorted_video"] == "dist.y4m"
+    assert os.path.basename(res["json_path"]).startswith("T_") and res["json_path"].endswith("_vmaf.json")
+    assert res["psnr_score"] == os.path.basename(res["psnr_log"]) and res["ssim_score"].endswith("_ssim.txt")
+    assert ev["progress"][0] == 0 and ev["progress"][-1] == 100
+    assert ev["status"][0] == "Analyzing videos with model: vmaf_v0.6.1" and ev["status"][-1].startswith("VMAF analysis complete! Score: ")
+    raw = res["raw_results"]
+    assert res["vmaf_score"] == raw["pooled_metrics"]["vmaf"]["mean"]
+    fr = raw["frames"]
+    assert [f["frameNum"] for f in fr] == [0, 1, 2, 3]
+    for k in ("integer_adm2", "integer_motion2", "integer_vif_scale0", "integer_vif_scale3", "vmaf", "psnr_y", "ssim"):
+        assert k in fr[0]["metrics"]
+    # scores are what the oracle + model give for these files
+    rec = np.zeros((4, 24)); rec[:, :17] = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], 8)
+    want = M.score_frames(M.load_model("vmaf_v0.6.1"), M.metrics_from_records(rec, 96, 64, "integer_"))["vmaf"]
+    np.testing.assert_allclose([f["metrics"]["vmaf"] for f in fr], want, atol=1e-6)
+    # stats files hold one FFmpeg-format line per frame
+    lines = open(res["psnr_log"]).read().strip().split("\n")
+    assert len(lines) == 4 and lines[0].startswith("n:1 mse_avg:") and "psnr_y:" in lines[3]
+    assert open(res["ssim_log"]).read().startswith("n:1 Y:")
+
+
+def test_analyzer_errors_and_options(tmp_path):
+    rp, dp, _, _ = _write_pair(tmp_path)
+    a, ev = _analyzer(tmp_path)
+    assert a.analyze_videos(str(tmp_path / "missing.y4m"), dp) is None
+    assert ev["errors"] == [f"Reference video not found: {tmp_path / 'missing.y4m'}"]
+    assert a.analyze(rp, str(tmp_path / "nope.y4m")) is None and "Distorted video not found" in ev["errors"][-1]
+    assert a.analyze_videos(rp, dp, "vmaf_does_not_exist") is None and "unknown VMAF model" in ev["errors"][-1]
+    # size mismatch is an error signal, not an exception
+    refs, _ = synth.make_clip(64, 48, 2, 8, chroma=True)
+    other = str(tmp_path / "small.y4m")
+    yuvio.write_y4m(other, refs, synth.clip_info(64, 48))
+    assert a.analyze_videos(rp, other) is None and "96x64" in ev["errors"][-1]
+
+    class OM:
+        def get_setting(self, k):
+            return {"threads": 8, "feature_subsample": 2, "pool_method": "harmonic_mean", "psnr_enabled": False,
+                    "ssim_enabled": False}
+    a.set_options_from_manager(OM())
+    assert (a.threads, a.feature_subsample, a.pool_method, a.psnr_enabled, a.ssim_enabled) == (8, 2, "harmonic_mean", False, False)
+    res = a.analyze_videos(rp, dp)
+    assert res["psnr_score"] == "Not Available" and res["psnr_log"] is None
+    assert [f["frameNum"] for f in res["raw_results"]["frames"]] == [0, 2]       # n_subsample=2
+    assert "psnr_y" not in res["raw_results"]["frames"][0]["metrics"]
+
+
+def test_analyzer_terminate_from_another_thread(tmp_path):
+    rp, dp, _, _ = _write_pair(tmp_path, n=6)
+    a, ev = _analyzer(tmp_path)
+
+    class SlowEngine(OracleEngine):
+        def submit(self, *args):
+            if len(self.rec) == 1:
+                threading.Thread(target=a.terminate_analysis).start()
+                import time
+                time.sleep(0.2)
+            return super().submit(*args)
+    a._engine_factory = SlowEngine
+    assert a.analyze_videos(rp, dp) is None
+    assert ev["errors"] == ["VMAF analysis was terminated by user"] and ev["complete"] == []
+    a._engine_factory = OracleEngine
+    assert a.analyze_videos(rp, dp) is not None      # a new analysis re-arms, like the reference (:254)

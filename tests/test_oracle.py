@@ -1,0 +1,124 @@
+"""Pins for the CPU oracle (oracle/vmaf_oracle.c).  No libvmaf/ffmpeg exists offline and the reference
+ships no golden vectors for this path ("parity unpinned"), so the oracle is held by: known constants
+of the published algorithms, closed-form answers, an independent numpy restatement, the SVM anchor,
+and committed regression fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_restatement as NP
+from oracle.oracle import finish_features, svr_predict_py
+from pqa2_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_filter_tables_match_published_libvmaf_constants(oracle32):
+    # libvmaf vif_filter1d_table (float) first taps and the Q16 integer tables quoted in SURVEY.md 8(a)
+    f17 = oracle32.gaussian_taps(17)
+    np.testing.assert_allclose(f17[:9], [0.00745626912, 0.0142655009, 0.0250313189, 0.0402820669, 0.0594526194,
+                                          0.0804751068, 0.0999041125, 0.113746084, 0.118773937], rtol=0, atol=1.5e-7)
+    # libvmaf's Q16 tables are these taps * 65536, nudged by <= 1 LSB so each table sums to exactly 65536
+    q17 = [489, 935, 1640, 2640, 3896, 5274, 6547, 7455, 7784]
+    assert 2 * sum(q17[:8]) + q17[8] == 65536
+    assert np.abs(f17[:9] * 65536 - q17).max() < 1.0
+    assert np.abs(oracle32.gaussian_taps(9)[:5] * 65536 - [1244, 3663, 7925, 12590, 14692]).max() < 1.0
+    assert np.abs(oracle32.gaussian_taps(5) * 65536 - [3571, 16004, 26386, 16004, 3571]).max() < 1.0
+    assert np.abs(oracle32.gaussian_taps(3) * 65536 - [10904, 43728, 10904]).max() < 1.0
+    for n in (17, 9, 5, 3):
+        assert abs(oracle32.gaussian_taps(n).sum() - 1.0) < 1e-6
+    # FILTER_5_s of libvmaf's motion
+    np.testing.assert_allclose(oracle32.gaussian_taps(5), [0.054488685, 0.244201342, 0.402619947, 0.244201342, 0.054488685], rtol=0, atol=1.5e-7)
+
+
+def test_adm_csf_factors_match_survey(oracle32):
+    rf = oracle32.adm_rfactors()
+    want = [[0.0173815, 0.0058907], [0.0319848, 0.0142991], [0.0433727, 0.0243969], [0.0456734, 0.0313127]]
+    np.testing.assert_allclose(rf, want, rtol=2e-5)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (97, 33), (176, 144)])
+def test_c_oracle_agrees_with_independent_numpy_restatement(oracle64, oracle32, w, h):
+    refs, diss = synth.make_clip(w, h, 2, 8, chroma=False)
+    pb = pn = None
+    for t in range(2):
+        f64, pb = oracle64.frame_features(refs[t][0], diss[t][0], 8, pb)
+        fn, pn = NP.frame_features(refs[t][0], diss[t][0], 8, pn)
+        np.testing.assert_allclose(f64, fn, rtol=5e-8, atol=1e-10)
+    f32, _ = oracle32.frame_features(refs[1][0], diss[1][0], 8, None)
+    np.testing.assert_allclose(f32[:16], f64[:16], rtol=2e-5)   # libvmaf's f32 arithmetic vs f64 truth
+
+
+def test_hbd_and_gain_limit_agree_with_numpy(oracle64):
+    refs, diss = synth.make_clip(120, 72, 1, 10, chroma=False)
+    f64, _ = oracle64.frame_features(refs[0][0], diss[0][0], 10, None, 1.0, 1.0)
+    fn, _ = NP.frame_features(refs[0][0], diss[0][0], 10, None, 1.0, 1.0)
+    np.testing.assert_allclose(f64, fn, rtol=5e-8, atol=1e-10)
+
+
+def test_closed_forms(oracle32):
+    refs, _ = synth.make_clip(96, 64, 1, 8, chroma=True)
+    y = refs[0][0]
+    f0, blur = oracle32.frame_features(y, y)
+    np.testing.assert_array_equal(f0[0:4], f0[4:8])        # identical -> vif num == den exactly
+    np.testing.assert_allclose(f0[8:12] / f0[12:16], 1.0, atol=1e-6)
+    f1, _ = oracle32.frame_features(y, y, 8, blur)
+    assert f1[16] == 0.0                                    # static clip -> motion 0
+    assert f0[16] == 0.0                                    # first frame -> motion 0
+    assert oracle32.sse_plane(y, y) == 0
+    c = 5
+    y2 = (y.astype(np.int32) // 2 + c).astype(np.uint8)
+    y1 = (y.astype(np.int32) // 2).astype(np.uint8)
+    assert oracle32.sse_plane(y1, y2) == c * c * y.size     # constant offset
+    assert abs(oracle32.ssim_plane(y, y) - 1.0) < 1e-12
+
+
+def test_ssim_and_sse_agree_with_numpy(oracle32):
+    for bpc in (8, 10):
+        refs, diss = synth.make_clip(130, 70, 1, bpc, chroma=True)
+        for p in range(3):
+            assert oracle32.sse_plane(diss[0][p], refs[0][p], bpc) == NP.sse_plane(diss[0][p], refs[0][p])
+            a = oracle32.ssim_plane(diss[0][p], refs[0][p], bpc)
+            b = NP.ssim_plane(diss[0][p], refs[0][p], bpc)
+            assert abs(a - b) < 2e-7   # C follows FFmpeg's float32 window ratio; numpy keeps float64
+
+
+def test_svm_anchor_and_motion2_rule():
+    with open(os.path.join(os.path.dirname(GOLD), "..", "pqa2_amd", "models", "vmaf_v0.6.1.json")) as f:
+        md = json.load(f)["model_dict"]
+    # the documented libvmaf value for identical frames at zero motion
+    assert abs(svr_predict_py(md, [1, 0, 1, 1, 1, 1]) - 97.428043) < 1e-6
+    rec = np.ones((4, 17)); rec[:, 16] = [0.0, 3.0, 1.0, 2.0]
+    out = finish_features(rec, 1920, 1080)
+    assert out["motion2"].tolist() == [0.0, 1.0, 1.0, 2.0]   # min(m_i, m_{i+1}); last keeps its own
+
+
+def test_golden_fixtures(oracle64, oracle32):
+    with open(os.path.join(GOLD, "golden_features.json")) as f:
+        gold = json.load(f)["cases"]
+    # the smallest case ships its bytes: no dependence on the generator
+    g = gold["c64x48_8"]
+    z = np.load(os.path.join(GOLD, "c64x48_8_frames.npz"))
+    refs = [[z[f"ref{i}_{p}"] for p in range(3)] for i in range(g["n"])]
+    diss = [[z[f"dis{i}_{p}"] for p in range(3)] for i in range(g["n"])]
+    rec = oracle64.clip_features([r[0] for r in refs], [d[0] for d in diss], 8)
+    np.testing.assert_allclose(rec, np.array(g["records"]), rtol=1e-12, atol=1e-12)
+    for i in range(g["n"]):
+        for p in range(3):
+            assert oracle32.sse_plane(diss[i][p], refs[i][p], 8) == g["sse"][i][p]
+            assert abs(oracle32.ssim_plane(diss[i][p], refs[i][p], 8) - g["ssim"][i][p]) < 1e-12
+    # the other cases regenerate their inputs; a different numpy RNG stream skips instead of failing
+    import hashlib
+    for name in ("c176x144_8", "c200x120_10"):
+        g = gold[name]
+        refs, diss = synth.make_clip(g["w"], g["h"], g["n"], g["bpc"], chroma=True)
+        sha = hashlib.sha256()
+        for fr in refs + diss:
+            for p in fr:
+                sha.update(np.ascontiguousarray(p).tobytes())
+        if sha.hexdigest() != g["input_sha256"]:
+            pytest.skip("synthetic generator produced different bytes on this numpy build")
+        rec = oracle64.clip_features([r[0] for r in refs], [d[0] for d in diss], g["bpc"])
+        np.testing.assert_allclose(rec, np.array(g["records"]), rtol=1e-12, atol=1e-12)
