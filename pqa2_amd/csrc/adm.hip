@@ -6,13 +6,15 @@
 // oracle/vmaf_oracle.c.
 //
 // One launch = one scale of a batch of frames, fully fused: the only HBM writes are the two
-// approximation bands the next scale needs and six partial doubles per tile.
-//   phase 1  vertical DWT: lane <-> input column, 14 input rows streamed per thread, lo/hi of ref and
-//            dis for 6 output rows -> LDS V[4][18][136]
-//   phase 2  horizontal DWT from LDS (2 x ds_read_b64 per array), then per coefficient: approximation
-//            band store, decouple, CSF; masking signal F = |csf(a)|/30 -> LDS, |csf(r)| stays in
-//            registers; denominator cube sums accumulate immediately
-//   phase 3  threshold = sum over orientations of (3x3 box of F + centre) from LDS, numerator cubes
+// approximation bands the next scale needs and six partial doubles per tile.  Reference and distorted
+// samples travel together as float2 = {ref, dis}, so every DWT tap is one v_pk_fma_f32 for both images
+// (FP32 FMA issues at the same rate packed or not on gfx950: tools/ubench/fma_rate.hip).
+//   phase 1  vertical DWT: lane <-> input column, rows addressed through SGPR offsets (buffer_load),
+//            20 input rows -> 9 output rows of {lo, hi} x {ref, dis} -> LDS
+//   phase 2  horizontal DWT (2 x ds_read_b128 per filter), then per coefficient: approximation band
+//            store, decouple, CSF; the masking signal summed over orientations -> LDS, |csf(r)| stays
+//            in registers; denominator cube sums accumulate immediately
+//   phase 3  threshold = 3x3 box of the masking signal + centre, numerator cubes
 // The tile carries a one-coefficient halo (66 x 18 for 64 x 16) so phase 3 never leaves LDS.
 #include "kernels.h"
 #include "pqa_device.h"
@@ -34,15 +36,19 @@ struct AdmArgs {
 };
 
 constexpr int TW = kAdmTileW, TH = kAdmTileH, GW = TW + 2, GH = TH + 2;
-constexpr int VC = 2 * TW + 6, VP = 136;  // vertical-pass columns / LDS pitch
-constexpr int NITEM = GW * GH, NROUND = (NITEM + kBlock - 1) / kBlock;
+constexpr int VC = 2 * GW + 2, VP = 136;  // vertical-pass columns / LDS pitch (float2)
+constexpr int SROWS = GH / 2;             // output rows per vertical strip (2 strips)
+constexpr int NIN = 2 * SROWS + 2;        // input rows per strip
+constexpr int NROUND = 5;                 // phase 2/3 rounds: 4.5 x (64 cols x 4 rows) + halo columns
+constexpr int GP = GW + 1;                // pitch of the masking-signal array
 
-__device__ __forceinline__ float clamp01(float k) { return k < 0.0f ? 0.0f : (k > 1.0f ? 1.0f : k); }
+__device__ __forceinline__ f2 splat(float c) { return f2{c, c}; }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void adm_scale_kernel(const AdmArgs a) {
-  __shared__ float V[4][GH][VP];  // vlo_ref, vhi_ref, vlo_dis, vhi_dis
-  __shared__ float F[3][GH][GW];  // masking signal per orientation
+__global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
+  __shared__ f2 Vlo[GH][VP];    // vertical low-pass  {ref, dis}
+  __shared__ f2 Vhi[GH][VP];    // vertical high-pass {ref, dis}
+  __shared__ float G[GH][GP];   // masking signal: sum over orientations of |csf(a)| / 30
   __shared__ double red[24];
 
   const float lo0 = 0.482962913144690f, lo1 = 0.836516303737469f, lo2 = 0.224143868041857f,
@@ -57,32 +63,57 @@ __global__ __launch_bounds__(kBlock) void adm_scale_kernel(const AdmArgs a) {
   const T* __restrict__ dis = (const T*)a.dis + (int64_t)fr * a.frame_pitch_d;
   const int cx0 = tx * TW, cy0 = ty * TH;
   const int tid = threadIdx.x;
+  const unsigned pitch_r = (unsigned)a.row_pitch_r, pitch_d = (unsigned)a.row_pitch_d;
+  const rsrc_t rsrc_r = make_rsrc(ref, (unsigned)a.h * pitch_r * (unsigned)sizeof(T));
+  const rsrc_t rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d * (unsigned)sizeof(T));
 
-  // ---- phase 1: vertical DWT ---------------------------------------------------------------
-  for (int item = tid; item < VC * 3; item += kBlock) {
-    const int col = item % VC, strip = item / VC;
-    const int gx = mirror(2 * cx0 - 3 + col, a.w);
-    float r[14], d[14];
+  // ---- phase 1: vertical DWT -------------------------------------------------------------------
+  // items: 128 columns x 2 strips in round 0, the last VC-128 columns x 2 strips in round 1 (wave 0 only)
+  for (int round = 0; round < 2; ++round) {
+    int col, strip;
+    if (round == 0) {
+      col = tid & 127;
+      strip = __builtin_amdgcn_readfirstlane(tid >> 7);
+    } else {
+      if (tid >= 2 * (VC - 128)) break;
+      col = 128 + (tid >> 1);
+      strip = tid & 1;
+    }
+    const unsigned gx = (unsigned)mirror1(2 * cx0 - 3 + col, a.w);
+    f2 x[NIN];
 #pragma unroll
-    for (int j = 0; j < 14; ++j) {
-      const int gy = mirror(2 * cy0 - 3 + 12 * strip + j, a.h);
-      r[j] = PixIO<T>::load(ref + (int64_t)gy * a.row_pitch_r + gx, a.inv_scale);
-      d[j] = PixIO<T>::load(dis + (int64_t)gy * a.row_pitch_d + gx, a.inv_scale);
+    for (int j = 0; j < NIN; ++j) {
+      const unsigned gy = (unsigned)mirror1(2 * cy0 - 3 + 2 * SROWS * strip + j, a.h);
+      T r, d;
+      if (round == 0) {  // strip is wave-uniform: the row offset rides in an SGPR
+        r = buf_load<T>(rsrc_r, gx, gy * pitch_r);
+        d = buf_load<T>(rsrc_d, gx, gy * pitch_d);
+      } else {           // 12 stragglers with per-lane strips: everything in the lane offset
+        r = buf_load<T>(rsrc_r, gx + gy * pitch_r, 0u);
+        d = buf_load<T>(rsrc_d, gx + gy * pitch_d, 0u);
+      }
+      x[j] = PixIO<T>::pair(r, d, a.inv_scale);
     }
 #pragma unroll
-    for (int o = 0; o < 6; ++o) {
-      const int lr = strip * 6 + o;
-      const float r0 = r[2 * o], r1 = r[2 * o + 1], r2 = r[2 * o + 2], r3 = r[2 * o + 3];
-      const float d0 = d[2 * o], d1 = d[2 * o + 1], d2 = d[2 * o + 2], d3 = d[2 * o + 3];
-      V[0][lr][col] = fmaf(lo3, r3, fmaf(lo2, r2, fmaf(lo1, r1, lo0 * r0)));
-      V[1][lr][col] = fmaf(hi3, r3, fmaf(hi2, r2, fmaf(hi1, r1, hi0 * r0)));
-      V[2][lr][col] = fmaf(lo3, d3, fmaf(lo2, d2, fmaf(lo1, d1, lo0 * d0)));
-      V[3][lr][col] = fmaf(hi3, d3, fmaf(hi2, d2, fmaf(hi1, d1, hi0 * d0)));
+    for (int o = 0; o < SROWS; ++o) {
+      const int lr = strip * SROWS + o;
+      // taps accumulate in libvmaf's order: ((c0*s0 + c1*s1) + c2*s2) + c3*s3
+      f2 vl = splat(lo0) * x[2 * o], vh = splat(hi0) * x[2 * o];
+      vl = __builtin_elementwise_fma(splat(lo1), x[2 * o + 1], vl);
+      vh = __builtin_elementwise_fma(splat(hi1), x[2 * o + 1], vh);
+      vl = __builtin_elementwise_fma(splat(lo2), x[2 * o + 2], vl);
+      vh = __builtin_elementwise_fma(splat(hi2), x[2 * o + 2], vh);
+      vl = __builtin_elementwise_fma(splat(lo3), x[2 * o + 3], vl);
+      vh = __builtin_elementwise_fma(splat(hi3), x[2 * o + 3], vh);
+      Vlo[lr][col] = vl;
+      Vhi[lr][col] = vh;
     }
   }
   __syncthreads();
 
   // ---- phase 2: horizontal DWT, decouple, CSF ------------------------------------------------
+  // grid of (GW x GH) coefficients incl. halo: rounds 0..3 take columns 1..64 x rows 4r..4r+3, round 4
+  // takes rows 16,17 of those columns (threads 0..127) and the two halo columns x 18 rows (threads 128..163)
   const float cos_1deg_sq = 0.99969541350954788f;  // cos(pi/180)^2
   const float eps = 1e-30f;
   float xs[NROUND][3];
@@ -90,48 +121,69 @@ __global__ __launch_bounds__(kBlock) void adm_scale_kernel(const AdmArgs a) {
   unsigned acc_mask = 0;
 #pragma unroll
   for (int k = 0; k < NROUND; ++k) {
-    const int item = tid + k * kBlock;
+    int lcx, lcy;
+    bool have = true;
+    if (k < 4) {
+      lcx = 1 + (tid & 63);
+      lcy = 4 * k + (tid >> 6);
+    } else if (tid < 128) {
+      lcx = 1 + (tid & 63);
+      lcy = 16 + (tid >> 6);
+    } else {
+      const int t = tid - 128;
+      have = t < 2 * GH;
+      lcx = (t & 1) ? GW - 1 : 0;
+      lcy = have ? (t >> 1) : 0;
+    }
     xs[k][0] = xs[k][1] = xs[k][2] = 0.0f;
-    if (item < NITEM) {
-      const int lcy = item / GW, lcx = item - lcy * GW;
+    if (have) {
       const int cx = cx0 - 1 + lcx, cy = cy0 - 1 + lcy;
       const bool valid = cx >= 0 && cx < a.ow && cy >= 0 && cy < a.oh;
-      float f_h = 0.0f, f_v = 0.0f, f_d = 0.0f;
+      float g = 0.0f;
       if (valid) {
-        float b[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float2 p0 = *reinterpret_cast<const float2*>(&V[q][lcy][2 * lcx]);
-          const float2 p1 = *reinterpret_cast<const float2*>(&V[q][lcy][2 * lcx + 2]);
-          b[q][0] = p0.x; b[q][1] = p0.y; b[q][2] = p1.x; b[q][3] = p1.y;
-        }
-#define PQA_LO(s) fmaf(lo3, s[3], fmaf(lo2, s[2], fmaf(lo1, s[1], lo0 * s[0])))
-#define PQA_HI(s) fmaf(hi3, s[3], fmaf(hi2, s[2], fmaf(hi1, s[1], hi0 * s[0])))
-        const float ra = PQA_LO(b[0]), ov = PQA_HI(b[0]), oh = PQA_LO(b[1]), od = PQA_HI(b[1]);
-        const float da = PQA_LO(b[2]), tv = PQA_HI(b[2]), th = PQA_LO(b[3]), td = PQA_HI(b[3]);
-#undef PQA_LO
-#undef PQA_HI
+        const f4* pl = reinterpret_cast<const f4*>(&Vlo[lcy][2 * lcx]);
+        const f4* ph = reinterpret_cast<const f4*>(&Vhi[lcy][2 * lcx]);
+        const f4 l01 = pl[0], l23 = pl[1], h01 = ph[0], h23 = ph[1];
+        const f2 l0 = f2{l01.x, l01.y}, l1 = f2{l01.z, l01.w}, l2 = f2{l23.x, l23.y}, l3 = f2{l23.z, l23.w};
+        const f2 h0 = f2{h01.x, h01.y}, h1 = f2{h01.z, h01.w}, h2 = f2{h23.x, h23.y}, h3 = f2{h23.z, h23.w};
+#define PQA_DWT(c0, c1, c2, c3, s0, s1, s2, s3)                                                        \
+  __builtin_elementwise_fma(splat(c3), s3,                                                             \
+                            __builtin_elementwise_fma(splat(c2), s2, __builtin_elementwise_fma(splat(c1), s1, splat(c0) * s0)))
+        const f2 ba = PQA_DWT(lo0, lo1, lo2, lo3, l0, l1, l2, l3);  // {ref, dis} approximation
+        const f2 bv = PQA_DWT(hi0, hi1, hi2, hi3, l0, l1, l2, l3);  // vertical   (lo-v, hi-h)
+        const f2 bh = PQA_DWT(lo0, lo1, lo2, lo3, h0, h1, h2, h3);  // horizontal (hi-v, lo-h)
+        const f2 bd = PQA_DWT(hi0, hi1, hi2, hi3, h0, h1, h2, h3);  // diagonal
+#undef PQA_DWT
         const bool inner = lcx >= 1 && lcx <= TW && lcy >= 1 && lcy <= TH;
         if (inner && a.ll_ref) {
-          a.ll_ref[(int64_t)fr * a.ll_frame_pitch_r + (int64_t)cy * a.ll_row_pitch_r + cx] = ra;
-          a.ll_dis[(int64_t)fr * a.ll_frame_pitch_d + (int64_t)cy * a.ll_row_pitch_d + cx] = da;
+          a.ll_ref[(int64_t)fr * a.ll_frame_pitch_r + (int64_t)cy * a.ll_row_pitch_r + cx] = ba.x;
+          a.ll_dis[(int64_t)fr * a.ll_frame_pitch_d + (int64_t)cy * a.ll_row_pitch_d + cx] = ba.y;
         }
-        // decouple
-        const float kh = clamp01(th / (oh + eps)), kv = clamp01(tv / (ov + eps)), kd = clamp01(td / (od + eps));
+        const float oh = bh.x, ov = bv.x, od = bd.x, th = bh.y, tv = bv.y, td = bd.y;
+        // decouple: k = clamp(t / (o + eps), 0, 1) via v_rcp_f32 + one Newton step; fmax/fmin drop a NaN
+        // (0 * inf when o + eps underflows), which the reference's comparisons would also map to 0
+        const float xh = oh + eps, xv = ov + eps, xd = od + eps;
+        const float rch = fast_rcp(xh), rcv = fast_rcp(xv), rcd = fast_rcp(xd);
+        float kh = th * rch, kv = tv * rcv, kd = td * rcd;
+        kh = fmaf(fmaf(-kh, xh, th), rch, kh);
+        kv = fmaf(fmaf(-kv, xv, tv), rcv, kv);
+        kd = fmaf(fmaf(-kd, xd, td), rcd, kd);
+        kh = fminf(fmaxf(kh, 0.0f), 1.0f);
+        kv = fminf(fmaxf(kv, 0.0f), 1.0f);
+        kd = fminf(fmaxf(kd, 0.0f), 1.0f);
         float rh = kh * oh, rv = kv * ov, rd = kd * od;
         const float ot_dp = oh * th + ov * tv;
         const float o_mag_sq = oh * oh + ov * ov, t_mag_sq = th * th + tv * tv;
         const bool angle_flag = (ot_dp >= 0.0f) && (ot_dp * ot_dp >= cos_1deg_sq * o_mag_sq * t_mag_sq);
         if (angle_flag) {
-          if (rh > 0.0f) rh = fminf(rh * a.gain_limit, th); else if (rh < 0.0f) rh = fmaxf(rh * a.gain_limit, th);
-          if (rv > 0.0f) rv = fminf(rv * a.gain_limit, tv); else if (rv < 0.0f) rv = fmaxf(rv * a.gain_limit, tv);
-          if (rd > 0.0f) rd = fminf(rd * a.gain_limit, td); else if (rd < 0.0f) rd = fmaxf(rd * a.gain_limit, td);
+          const float gh = rh * a.gain_limit, gv = rv * a.gain_limit, gd = rd * a.gain_limit;
+          rh = rh > 0.0f ? fminf(gh, th) : (rh < 0.0f ? fmaxf(gh, th) : rh);
+          rv = rv > 0.0f ? fminf(gv, tv) : (rv < 0.0f ? fmaxf(gv, tv) : rv);
+          rd = rd > 0.0f ? fminf(gd, td) : (rd < 0.0f ? fmaxf(gd, td) : rd);
         }
-        const float ah = th - rh, av = tv - rv, ad = td - rd;
-        // CSF of the additive image -> masking signal
-        f_h = (1.0f / 30.0f) * fabsf(a.rf_hv * ah);
-        f_v = (1.0f / 30.0f) * fabsf(a.rf_hv * av);
-        f_d = (1.0f / 30.0f) * fabsf(a.rf_d * ad);
+        // CSF of the additive image; adm_cm_s sums the 3x3 boxes per orientation and then over
+        // orientations -- summing over orientations first is the same value up to float rounding
+        g = (1.0f / 30.0f) * (fabsf(a.rf_hv * (th - rh)) + fabsf(a.rf_hv * (tv - rv)) + fabsf(a.rf_d * (td - rd)));
         if (inner && cx >= a.left && cx < a.right && cy >= a.top && cy < a.bottom) {
           acc_mask |= 1u << k;
           xs[k][0] = fabsf(rh * a.rf_hv);
@@ -143,9 +195,7 @@ __global__ __launch_bounds__(kBlock) void adm_scale_kernel(const AdmArgs a) {
           den_d += vd * vd * vd;
         }
       }
-      F[0][lcy][lcx] = f_h;
-      F[1][lcy][lcx] = f_v;
-      F[2][lcy][lcx] = f_d;
+      G[lcy][lcx] = g;
     }
   }
   __syncthreads();
@@ -153,33 +203,41 @@ __global__ __launch_bounds__(kBlock) void adm_scale_kernel(const AdmArgs a) {
   // ---- phase 3: contrast masking -------------------------------------------------------------
   float num_h = 0.0f, num_v = 0.0f, num_d = 0.0f;
 #pragma unroll
-  for (int k = 0; k < NROUND; ++k) {
+  for (int k = 0; k < NROUND - 1; ++k) {  // inner coefficients only live in rounds 0..4; round 4 rows 16 only
     if (acc_mask & (1u << k)) {
-      const int item = tid + k * kBlock;
-      const int lcy = item / GW, lcx = item - lcy * GW;
+      const int lcx = 1 + (tid & 63), lcy = 4 * k + (tid >> 6);
       const int cx = cx0 - 1 + lcx, cy = cy0 - 1 + lcy;
       // band-level mirror of the 3x3 neighbourhood (only bites when the window touches the border)
-      const int ly[3] = {mirror(cy - 1, a.oh) - (cy0 - 1), lcy, mirror(cy + 1, a.oh) - (cy0 - 1)};
-      const int lx[3] = {mirror(cx - 1, a.ow) - (cx0 - 1), lcx, mirror(cx + 1, a.ow) - (cx0 - 1)};
-      float thr = 0.0f;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        float sum1 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) sum1 += F[t][ly[i]][lx[j]];
-        sum1 += F[t][lcy][lcx];
-        thr += sum1;
-      }
+      const int ly0 = mirror1(cy - 1, a.oh) - (cy0 - 1), ly2 = mirror1(cy + 1, a.oh) - (cy0 - 1);
+      const int lx0 = mirror1(cx - 1, a.ow) - (cx0 - 1), lx2 = mirror1(cx + 1, a.ow) - (cx0 - 1);
+      const float c = G[lcy][lcx];
+      float thr = G[ly0][lx0] + G[ly0][lcx] + G[ly0][lx2];
+      thr += G[lcy][lx0] + c + G[lcy][lx2];
+      thr += G[ly2][lx0] + G[ly2][lcx] + G[ly2][lx2];
+      thr += c;
       float xh = xs[k][0] - thr, xv = xs[k][1] - thr, xd = xs[k][2] - thr;
-      xh = xh < 0.0f ? 0.0f : xh;
-      xv = xv < 0.0f ? 0.0f : xv;
-      xd = xd < 0.0f ? 0.0f : xd;
+      xh = fmaxf(xh, 0.0f);
+      xv = fmaxf(xv, 0.0f);
+      xd = fmaxf(xd, 0.0f);
       num_h += xh * xh * xh;
       num_v += xv * xv * xv;
       num_d += xd * xd * xd;
     }
+  }
+  if (acc_mask & (1u << 4)) {  // row 16 of the halo'd grid (last inner row), threads 0..63
+    const int lcx = 1 + (tid & 63), lcy = 16 + (tid >> 6);
+    const int cx = cx0 - 1 + lcx, cy = cy0 - 1 + lcy;
+    const int ly0 = mirror1(cy - 1, a.oh) - (cy0 - 1), ly2 = mirror1(cy + 1, a.oh) - (cy0 - 1);
+    const int lx0 = mirror1(cx - 1, a.ow) - (cx0 - 1), lx2 = mirror1(cx + 1, a.ow) - (cx0 - 1);
+    const float c = G[lcy][lcx];
+    float thr = G[ly0][lx0] + G[ly0][lcx] + G[ly0][lx2];
+    thr += G[lcy][lx0] + c + G[lcy][lx2];
+    thr += G[ly2][lx0] + G[ly2][lcx] + G[ly2][lx2];
+    thr += c;
+    const float xh = fmaxf(xs[4][0] - thr, 0.0f), xv = fmaxf(xs[4][1] - thr, 0.0f), xd = fmaxf(xs[4][2] - thr, 0.0f);
+    num_h += xh * xh * xh;
+    num_v += xv * xv * xv;
+    num_d += xd * xd * xd;
   }
   double v[6] = {(double)num_h, (double)num_v, (double)num_d, (double)den_h, (double)den_v, (double)den_d};
   block_sum<6>(v, red);

@@ -5,6 +5,9 @@
 
 namespace pqa {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
 constexpr int kWave = 64;
 constexpr int kBlock = 256;  // 4 waves per workgroup everywhere
 
@@ -20,21 +23,55 @@ __device__ __forceinline__ int mirror(int i, int n) {
   return i;
 }
 
+// Buffer addressing: a 128-bit resource (base + size, built from wave-uniform values) with the column
+// offset in a VGPR and the row offset in an SGPR.  One plane row costs zero VALU address arithmetic and
+// out-of-range offsets read 0 instead of faulting.  Offsets are in ELEMENTS here.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ T buf_load(rsrc_t r, unsigned lane_off, unsigned row_off);
+template <> __device__ __forceinline__ uint8_t buf_load<uint8_t>(rsrc_t r, unsigned lane_off, unsigned row_off) {
+  return __builtin_amdgcn_raw_buffer_load_b8(r, lane_off, row_off, 0);
+}
+template <> __device__ __forceinline__ uint16_t buf_load<uint16_t>(rsrc_t r, unsigned lane_off, unsigned row_off) {
+  return __builtin_amdgcn_raw_buffer_load_b16(r, lane_off * 2u, row_off * 2u, 0);
+}
+template <> __device__ __forceinline__ float buf_load<float>(rsrc_t r, unsigned lane_off, unsigned row_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off * 4u, row_off * 4u, 0));
+}
+
+// Same rule with a single fold and a clamp.  Exact whenever n > the stencil radius (every plane the
+// library accepts: w, h >= 16 at scale 0 and >= 2 at the deepest scale); indices further out belong to
+// tile positions beyond the image whose results are masked, they only need to stay in bounds.
+__device__ __forceinline__ int mirror1(int i, int n) {
+  i = i < 0 ? -i : i;
+  i = i >= n ? 2 * n - i - 1 : i;
+  return min(max(i, 0), n - 1);
+}
+
 // luma sample -> float as libvmaf picture_copy does: v * inv_scale - 128 (inv_scale = 2^-(bpc-8)).
 template <typename T> struct PixIO;
 template <> struct PixIO<uint8_t> {
   static __device__ __forceinline__ float load(const uint8_t* p, float) { return (float)(*p) - 128.0f; }
   static __device__ __forceinline__ float raw(const uint8_t* p) { return (float)(*p); }
+  static __device__ __forceinline__ f2 pair(uint8_t r, uint8_t d, float) {
+    return f2{(float)r, (float)d} + f2{-128.0f, -128.0f};
+  }
 };
 template <> struct PixIO<uint16_t> {
   static __device__ __forceinline__ float load(const uint16_t* p, float inv_scale) {
     return (float)(*p) * inv_scale - 128.0f;
   }
   static __device__ __forceinline__ float raw(const uint16_t* p) { return (float)(*p); }
+  static __device__ __forceinline__ f2 pair(uint16_t r, uint16_t d, float inv_scale) {
+    return f2{(float)r, (float)d} * f2{inv_scale, inv_scale} + f2{-128.0f, -128.0f};
+  }
 };
 template <> struct PixIO<float> {
   static __device__ __forceinline__ float load(const float* p, float) { return *p; }
   static __device__ __forceinline__ float raw(const float* p) { return *p; }
+  static __device__ __forceinline__ f2 pair(float r, float d, float) { return f2{r, d}; }
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give each XCD a

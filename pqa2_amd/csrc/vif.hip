@@ -39,6 +39,23 @@ static Taps gaussian_taps(int n) {
   return t;
 }
 
+// Tap table of the packed vertical pass: ct[k] = {c[k], c[k-1]} with c[-1] = c[N] = 0, so one
+// v_pk_fma_f32 with the input broadcast updates the two rows of a row pair in libvmaf's tap order.
+struct TapPairs {
+  f2 vt[18];  // vertical:   {c[k], c[k-1]}
+  f2 ht[17];  // horizontal: {c[k], c[k]}  (ready-made SGPR pairs: no splat moves, no op_sel juggling)
+};
+
+static TapPairs tap_pairs(const Taps& t, int n) {
+  TapPairs p{};
+  for (int k = 0; k <= n; ++k) {
+    p.vt[k].x = k < n ? t.f[k] : 0.0f;
+    p.vt[k].y = k > 0 ? t.f[k - 1] : 0.0f;
+  }
+  for (int k = 0; k < n; ++k) p.ht[k] = f2{t.f[k], t.f[k]};
+  return p;
+}
+
 struct VifStatArgs {
   const void* ref;
   const void* dis;
@@ -46,17 +63,22 @@ struct VifStatArgs {
   int w, h, tiles_x, n_tiles;
   float inv_scale, gain_limit;
   double* partials;
-  Taps taps;
+  TapPairs taps;
 };
 
-constexpr int kP = 130;  // LDS row pitch in floats: == 2 (mod 64) -> ds_read_b64 rows land 2 banks apart
+constexpr int kP2 = 130;  // LDS row pitch in float2: == 2 (mod 32) -> conflict-free ds_read_b128 (see below)
 
+// FP32 on gfx950 issues one wave64 VALU instruction per 4 cycles per SIMD; v_pk_fma_f32 does two FMAs
+// in that slot (measured: 74 TFLOP/s with v_fma_f32, 132-137 with v_pk_fma_f32, tools/ubench/fma_rate.hip).
+// Everything hot is therefore arranged as float2 = {row 2p, row 2p+1} of one column:
+//   vertical pass:   acc{2p,2p+1} += {c[k], c[k-1]} * {x, x}     (tap PAIR from SGPRs, input broadcast)
+//   horizontal pass: out{2p,2p+1}[o] += c[k] * in{2p,2p+1}[o+k]  (tap broadcast, input pair from LDS)
 template <typename T, int N, int TW>
-__global__ __launch_bounds__(kBlock) void vif_stat_kernel(const VifStatArgs a) {
-  constexpr int R = N / 2, TH = kVifTileH, COLS = TW + N - 1, NSEG = TW / 8, S = 8, NIN = S + N - 1;
-  static_assert(COLS <= 128 && COLS <= kP, "tile too wide");
-  static_assert(TW % 8 == 0 && NSEG <= 16, "segment map");
-  __shared__ float sv[5][TH][kP];
+__global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a) {
+  constexpr int R = N / 2, TH = kVifTileH, COLS = TW + N - 1, NSEG = TW / 4, S = 8, NIN = S + N - 1;
+  static_assert(COLS <= 128 && COLS <= kP2, "tile too wide");
+  static_assert(TW % 4 == 0 && NSEG <= 32 && TH == 16, "segment map");
+  __shared__ f2 sv[5][TH / 2][kP2];  // [signal][row pair][column] = {row 2p, row 2p+1}
   __shared__ double red[8];
 
   const int tile = xcd_remap(blockIdx.x, a.n_tiles);
@@ -67,99 +89,142 @@ __global__ __launch_bounds__(kBlock) void vif_stat_kernel(const VifStatArgs a) {
   const int x0 = tx * TW, y0 = ty * TH;
   const int tid = threadIdx.x;
 
-  // ---- 1. vertical pass --------------------------------------------------------------------
+  // ---- 1. vertical pass: lane <-> column, wave-uniform row addressing ---------------------------
   {
-    const int col = tid & 127, seg = tid >> 7;
+    const int col = tid & 127;
+    const int seg = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform: rows stay in SGPRs
     if (col < COLS) {
-      const int gx = mirror(x0 - R + col, a.w);
-      float r[NIN], d[NIN];
+      const unsigned gx = (unsigned)mirror1(x0 - R + col, a.w);
+      const unsigned pitch_r = (unsigned)a.row_pitch_r, pitch_d = (unsigned)a.row_pitch_d;  // planes < 4 G samples
+      const auto rsrc_r = make_rsrc(ref, (unsigned)a.h * pitch_r * (unsigned)sizeof(T));
+      const auto rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d * (unsigned)sizeof(T));
+      f2 acc[S / 2][5];
 #pragma unroll
-      for (int j = 0; j < NIN; ++j) {
-        const int gy = mirror(y0 + seg * S - R + j, a.h);
-        r[j] = PixIO<T>::load(ref + (int64_t)gy * a.row_pitch_r + gx, a.inv_scale);
-        d[j] = PixIO<T>::load(dis + (int64_t)gy * a.row_pitch_d + gx, a.inv_scale);
-      }
-      float acc[S][5];
+      for (int p = 0; p < S / 2; ++p)
 #pragma unroll
-      for (int o = 0; o < S; ++o)
+        for (int s = 0; s < 5; ++s) acc[p][s] = f2{0.0f, 0.0f};
+      // Input rows stream through in groups of G: the loads of group g+1 are in flight while group g is
+      // consumed; sched_barrier keeps hipcc from hoisting all 2*NIN loads (and their r*r, d*d, r*d) to
+      // the top, which costs ~120 VGPRs and a wave of occupancy.
+      constexpr int G = 4, NG = (NIN + G - 1) / G;
+      T rn[G], dn[G];
+      auto issue = [&](int g) {
 #pragma unroll
-        for (int s = 0; s < 5; ++s) acc[o][s] = 0.0f;
-#pragma unroll
-      for (int j = 0; j < NIN; ++j) {
-        const float rr = r[j] * r[j], dd = d[j] * d[j], rd = r[j] * d[j];
-#pragma unroll
-        for (int o = 0; o < S; ++o) {
-          const int k = j - o;  // tap index: increases with j, so each output sums taps 0..N-1 in order
-          if (k >= 0 && k < N) {
-            const float c = a.taps.f[k];
-            acc[o][0] = fmaf(c, r[j], acc[o][0]);
-            acc[o][1] = fmaf(c, d[j], acc[o][1]);
-            acc[o][2] = fmaf(c, rr, acc[o][2]);
-            acc[o][3] = fmaf(c, dd, acc[o][3]);
-            acc[o][4] = fmaf(c, rd, acc[o][4]);
+        for (int i = 0; i < G; ++i) {
+          const int j = g * G + i;
+          if (j < NIN) {
+            const unsigned gy = (unsigned)mirror1(y0 + seg * S - R + j, a.h);
+            // scalar frame base + 32-bit (row * pitch + column) lane offset -> global_load with an SGPR base
+            // buffer_load: lane offset (column) in a VGPR, row offset in an SGPR -> no per-load VALU
+            rn[i] = buf_load<T>(rsrc_r, gx, gy * pitch_r);
+            dn[i] = buf_load<T>(rsrc_d, gx, gy * pitch_d);
           }
         }
+      };
+      issue(0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        T rc[G], dc[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) { rc[i] = rn[i]; dc[i] = dn[i]; }
+        if (g + 1 < NG) issue(g + 1);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int j = g * G + i;
+          if (j < NIN) {
+            const f2 x = PixIO<T>::pair(rc[i], dc[i], a.inv_scale);  // {r, d} - 128 (one v_pk_add / v_pk_fma)
+            const f2 xx = x * x;                                      // {r*r, d*d}   (one v_pk_mul)
+            const float r = x.x, d = x.y, rr = xx.x, dd = xx.y, rd = x.x * x.y;
+#pragma unroll
+            for (int p = 0; p < S / 2; ++p) {
+              const int k = j - 2 * p;  // row 2p takes tap k, row 2p+1 tap k-1: both sum taps in increasing order
+              if (k >= 0 && k <= N) {
+                const f2 c = a.taps.vt[k];
+                acc[p][0] = __builtin_elementwise_fma(c, f2{r, r}, acc[p][0]);
+                acc[p][1] = __builtin_elementwise_fma(c, f2{d, d}, acc[p][1]);
+                acc[p][2] = __builtin_elementwise_fma(c, f2{rr, rr}, acc[p][2]);
+                acc[p][3] = __builtin_elementwise_fma(c, f2{dd, dd}, acc[p][3]);
+                acc[p][4] = __builtin_elementwise_fma(c, f2{rd, rd}, acc[p][4]);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int o = 0; o < S; ++o)
+      for (int p = 0; p < S / 2; ++p)
 #pragma unroll
-        for (int s = 0; s < 5; ++s) sv[s][seg * S + o][col] = acc[o][s];
+        for (int s = 0; s < 5; ++s) sv[s][seg * (S / 2) + p][col] = acc[p][s];
     }
   }
   __syncthreads();
 
-  // ---- 2. horizontal pass + 3. statistic ------------------------------------------------------
+  // ---- 2. horizontal pass + 3. statistic --------------------------------------------------------
+  // lane l: row pair l & 7, segment (4 columns) wave + 4 * (l >> 3).  With the 130-float2 pitch the
+  // 16-B chunk index of a lane is (rp + 8 * (j & 1) + const) mod 16: distinct inside every ds_read_b128
+  // lane group, i.e. conflict-free.
   const int wave = tid >> 6, lane = tid & 63;
-  const int row = lane & 15, seg = wave + 4 * (lane >> 4);
+  const int rp = lane & 7, seg = wave + 4 * (lane >> 3);
   float num = 0.0f, den = 0.0f;
   if (seg < NSEG) {
-    constexpr int NREAD = (8 + N - 1 + 1) / 2;  // float2 reads per signal
-    float out[5][8];
+    constexpr int NCOL = 4 + N - 1, NREAD = (NCOL + 1) / 2;
+    f2 out[5][4];
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      float in[2 * NREAD];
-      const float2* p = reinterpret_cast<const float2*>(&sv[s][row][seg * 8]);
+      f2 in[2 * NREAD];
+      const f4* p = reinterpret_cast<const f4*>(&sv[s][rp][seg * 4]);
 #pragma unroll
       for (int q = 0; q < NREAD; ++q) {
-        const float2 v = p[q];
-        in[2 * q] = v.x;
-        in[2 * q + 1] = v.y;
+        const f4 v = p[q];
+        in[2 * q] = f2{v.x, v.y};
+        in[2 * q + 1] = f2{v.z, v.w};
       }
+      // tap-major order: the four outputs are independent chains, so consecutive v_pk_fma_f32 never
+      // depend on each other (a dependent pair costs an s_nop); each output still sums taps 0..N-1 in order
 #pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        float acc = 0.0f;
+      for (int o = 0; o < 4; ++o) out[s][o] = f2{0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < N; ++k) acc = fmaf(a.taps.f[k], in[o + k], acc);
-        out[s][o] = acc;
-      }
+      for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) out[s][o] = __builtin_elementwise_fma(a.taps.ht[k], in[o + k], out[s][o]);
+      __builtin_amdgcn_sched_barrier(0);  // one signal's 10 ds_read_b128 in flight at a time, not all 50
     }
-    const int gy = y0 + row;
     const float sigma_nsq = 2.0f, eps = 1.0e-10f, sigma_max_inv = 4.0f / (255.0f * 255.0f);
+    // validity as 0/1 weights folded into the accumulation (an fma instead of an add): no branches, and
+    // out-of-image positions of edge tiles still hold finite values (mirrored real pixels)
+    const int gyA = y0 + 2 * rp;
+    const float mrow[2] = {gyA < a.h ? 1.0f : 0.0f, gyA + 1 < a.h ? 1.0f : 0.0f};
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      const int gx = x0 + seg * 8 + o;
-      const float mu1 = out[0][o], mu2 = out[1][o];
-      float sigma1_sq = out[2][o] - mu1 * mu1;
-      float sigma2_sq = out[3][o] - mu2 * mu2;
-      const float sigma12 = out[4][o] - mu1 * mu2;
-      sigma1_sq = fmaxf(sigma1_sq, 0.0f);
-      sigma2_sq = fmaxf(sigma2_sq, 0.0f);
-      // g = sigma12 / (sigma1_sq + eps): v_rcp_f32 plus one Newton correction -- exact 1.0 when the two
-      // are equal (identical frames => vif_scale == 1 exactly, as in libvmaf), 2 FMAs instead of a full div
-      const float gden = sigma1_sq + eps, grcp = fast_rcp(gden);
-      float g = sigma12 * grcp;
-      g = fmaf(fmaf(-g, gden, sigma12), grcp, g);
-      float sv_sq = sigma2_sq - g * sigma12;
-      if (sigma1_sq < eps) { g = 0.0f; sv_sq = sigma2_sq; sigma1_sq = 0.0f; }
-      if (sigma2_sq < eps) { g = 0.0f; sv_sq = 0.0f; }
-      if (g < 0.0f) { sv_sq = sigma2_sq; g = 0.0f; }
-      sv_sq = fmaxf(sv_sq, eps);
-      g = fminf(g, a.gain_limit);
-      float num_val = fast_log2(1.0f + (g * g * sigma1_sq) * fast_rcp(sv_sq + sigma_nsq));
-      float den_val = fast_log2(1.0f + sigma1_sq * (1.0f / sigma_nsq));
-      if (sigma12 < 0.0f) num_val = 0.0f;
-      if (sigma1_sq < sigma_nsq) { num_val = 1.0f - sigma2_sq * sigma_max_inv; den_val = 1.0f; }
-      if (gx < a.w && gy < a.h) { num += num_val; den += den_val; }
+    for (int o = 0; o < 4; ++o) {
+      const float mcol = (x0 + seg * 4 + o) < a.w ? 1.0f : 0.0f;
+      const f2 mu1 = out[0][o], mu2 = out[1][o];
+      const f2 s1v = out[2][o] - mu1 * mu1, s2v = out[3][o] - mu2 * mu2, s12v = out[4][o] - mu1 * mu2;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float sigma1_sq = fmaxf(s1v[e], 0.0f);
+        const float sigma2_sq = fmaxf(s2v[e], 0.0f);
+        const float sigma12 = s12v[e];
+        // g = sigma12 / (sigma1_sq + eps): v_rcp_f32 plus one Newton correction -- exact 1.0 when the two
+        // are equal (identical frames), 2 FMAs instead of a full IEEE division
+        const float gden = sigma1_sq + eps, grcp = fast_rcp(gden);
+        float g = sigma12 * grcp;
+        g = fmaf(fmaf(-g, gden, sigma12), grcp, g);
+        float sv_sq = sigma2_sq - g * sigma12;
+        // vif_statistic_s also has `if (sigma1_sq < eps) {g = 0; sv_sq = sigma2_sq; sigma1_sq = 0}` and
+        // `if (g < 0) {sv_sq = sigma2_sq; g = 0}`.  Both are dead for the result: the first implies
+        // sigma1_sq < sigma_nsq and the second implies sigma12 < 0, and each of those overrides num/den below.
+        if (sigma2_sq < eps) { g = 0.0f; sv_sq = 0.0f; }
+        sv_sq = fmaxf(sv_sq, eps);
+        g = fminf(g, a.gain_limit);
+        float num_val = fast_log2(1.0f + (g * g * sigma1_sq) * fast_rcp(sv_sq + sigma_nsq));
+        float den_val = fast_log2(1.0f + sigma1_sq * (1.0f / sigma_nsq));
+        if (sigma12 < 0.0f) num_val = 0.0f;
+        if (sigma1_sq < sigma_nsq) { num_val = 1.0f - sigma2_sq * sigma_max_inv; den_val = 1.0f; }
+        const float m = mcol * mrow[e];
+        num = fmaf(m, num_val, num);
+        den = fmaf(m, den_val, den);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // two pixels' worth of temporaries live at a time
     }
   }
   double v[2] = {(double)num, (double)den};
@@ -269,7 +334,7 @@ hipError_t launch_dec_n(hipStream_t stream, Elem elem, const VifDecArgs& a, int 
 }
 
 constexpr int kVifN[4] = {17, 9, 5, 3};
-constexpr int kVifTW[4] = {112, 120, 120, 120};
+constexpr int kVifTW[4] = {112, 120, 124, 124};
 
 }  // namespace
 
@@ -287,12 +352,12 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
   a.n_tiles = a.tiles_x * vif_tiles_y(h);
   a.inv_scale = inv_scale; a.gain_limit = gain_limit;
   a.partials = partials;
-  a.taps = gaussian_taps(kVifN[scale]);
+  a.taps = tap_pairs(gaussian_taps(kVifN[scale]), kVifN[scale]);
   switch (scale) {
     case 0: return launch_stat_n<17, 112>(stream, elem, a, n_frames);
     case 1: return launch_stat_n<9, 120>(stream, elem, a, n_frames);
-    case 2: return launch_stat_n<5, 120>(stream, elem, a, n_frames);
-    case 3: return launch_stat_n<3, 120>(stream, elem, a, n_frames);
+    case 2: return launch_stat_n<5, 124>(stream, elem, a, n_frames);
+    case 3: return launch_stat_n<3, 124>(stream, elem, a, n_frames);
   }
   return hipErrorInvalidValue;
 }
