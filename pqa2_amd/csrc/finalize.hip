@@ -1,5 +1,5 @@
 // Second-stage reduction: every per-tile partial of a batch -> one 24-slot record per frame.
-// One workgroup per frame walks each partial array in a FIXED order (thread-strided, then the same
+// One workgroup per (frame, quantity group) walks each partial array in a FIXED order (thread-strided, then the same
 // shuffle/LDS tree), so a frame's record does not depend on batch size, launch order or GPU count:
 // 1-, 2-, 4- and 8-GPU runs are bit-identical.  Record layout: include/pqa_vmaf.h (PQA_REC_*).
 #include "kernels.h"
@@ -20,20 +20,23 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) 
   __shared__ double red[4];
   __shared__ unsigned long long redu[4];
   const int fr = blockIdx.x;
+  const int grp = blockIdx.y;  // 0..3 vif scale, 4..7 adm scale, 8 motion + ssim + sse
   const int row = (int)(((int64_t)a.slot_base + (int64_t)fr * a.slot_step) % a.capacity);
   double* rec = a.records + (int64_t)row * a.record_stride;
   const int tid = threadIdx.x;
 
-  if (a.has_vif) {
-    for (int s = 0; s < 4; ++s) {
+  if (a.has_vif && grp < 4) {
+    {
+      const int s = grp;
       const double* p = a.vif_part[s] + (int64_t)fr * a.vif_tiles[s] * 2;
       const double num = reduce_strided(p, a.vif_tiles[s], 2, red);
       const double den = reduce_strided(p + 1, a.vif_tiles[s], 2, red);
       if (tid == 0) { rec[0 + s] = num; rec[4 + s] = den; }
     }
   }
-  if (a.has_adm) {
-    for (int s = 0; s < 4; ++s) {
+  if (a.has_adm && grp >= 4 && grp < 8) {
+    {
+      const int s = grp - 4;
       const double* p = a.adm_part[s] + (int64_t)fr * a.adm_tiles[s] * 6;
       double q[6];
       for (int i = 0; i < 6; ++i) q[i] = reduce_strided(p + i, a.adm_tiles[s], 6, red);
@@ -45,6 +48,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) 
       }
     }
   }
+  if (grp != 8) return;
   if (a.has_motion) {
     const double sad = reduce_strided(a.motion_part + (int64_t)fr * a.motion_tiles, a.motion_tiles, 1, red);
     if (tid == 0) rec[16] = sad * a.motion_norm;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) 
 
 hipError_t launch_finalize(hipStream_t stream, const FinalizeArgs& args) {
   if (args.n_frames <= 0) return hipSuccess;
-  hipLaunchKernelGGL(finalize_kernel, dim3(args.n_frames), dim3(kBlock), 0, stream, args);
+  hipLaunchKernelGGL(finalize_kernel, dim3(args.n_frames, 9), dim3(kBlock), 0, stream, args);
   return hipGetLastError();
 }
 

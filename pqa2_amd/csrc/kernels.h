@@ -31,10 +31,13 @@ inline int vif_tiles_x(int scale, int w) { return (w + vif_tile_w(scale) - 1) / 
 inline int vif_tiles_y(int h) { return (h + kVifTileH - 1) / kVifTileH; }
 
 // partials: [n_frames][tiles][2] doubles (num, den), tiles = tiles_x * tiles_y.
+// For scale < 3 the same launch also produces the next scale's input (fused decimation): the planes are
+// filtered with the next scale's kernel and even samples kept -> next_ref / next_dis, (w/2 x h/2) f32.
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
-                           int w, int h, float inv_scale, float gain_limit, double* partials);
+                           int w, int h, float inv_scale, float gain_limit, double* partials,
+                           MutPlaneRun next_ref, MutPlaneRun next_dis);
 
-// Filters (w x h) planes with the NEXT scale's kernel and keeps even samples -> (w/2 x h/2) f32.
+// Stand-alone decimation (same arithmetic as the fused path; kept for tests and profiling A/B).
 hipError_t launch_vif_decimate(hipStream_t stream, int dst_scale, Elem elem, PlaneRun ref, PlaneRun dis,
                                int n_frames, int w, int h, float inv_scale, MutPlaneRun dst_ref,
                                MutPlaneRun dst_dis);
@@ -53,7 +56,7 @@ hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun r
                             MutPlaneRun ll_dis, double* partials);
 
 // ---- motion ---------------------------------------------------------------------------------
-constexpr int kMotionTileW = 120, kMotionTileH = 16;
+constexpr int kMotionTileW = 124, kMotionTileH = 16;
 inline int motion_tiles(int w, int h) {
   return ((w + kMotionTileW - 1) / kMotionTileW) * ((h + kMotionTileH - 1) / kMotionTileH);
 }
@@ -85,7 +88,7 @@ struct FinalizeArgs {
   int has_vif, has_adm, has_motion, n_sse_planes, n_ssim_planes;
   const double* vif_part[4];   int vif_tiles[4];
   const double* adm_part[4];   int adm_tiles[4];   float adm_area[4];  // cropped-window area per scale
-  const double* motion_part;   int motion_tiles;   double motion_norm;  // 1/(w*h)
+  const double* motion_part;   int motion_tiles;   double motion_norm;  // 2^-(bpc-8) / (w*h)
   const unsigned long long* sse_part[3];
   const double* ssim_part[3];  int ssim_tiles[3];  double ssim_norm[3]; // 1/(windows)
   double* records;             // [capacity][record_stride] ring

@@ -20,16 +20,22 @@ struct MotionArgs {
   const void* prev0;
   int64_t prev0_row_pitch;
   int w, h, tiles_x, n_tiles;
-  float inv_scale;
   double* partials;
-  float f[5];
+  f2 vt[6];  // vertical tap pairs {c[k], c[k-1]}, c[-1] = c[5] = 0
+  f2 ht[5];  // horizontal splats {c[k], c[k]}
 };
 
-constexpr int TW = kMotionTileW, TH = kMotionTileH, R = 2, COLS = TW + 4, P = 130, NSEG = TW / 8, S = 8, NIN = S + 4;
+constexpr int TW = kMotionTileW, TH = kMotionTileH, R = 2, COLS = TW + 4, NSEG = TW / 4, S = 8, NIN = S + 4;
+constexpr int kP2 = 130;  // float2 pitch == 2 (mod 32): conflict-free ds_read_b128 (same map as vif.hip)
+static_assert(COLS <= 128 && NSEG <= 32 && TW % 4 == 0, "tile map");
 
+// Same packed layout as the VIF kernel: float2 = {row 2p, row 2p+1} of one column; the vertical pass
+// uses tap pairs with the input broadcast, the horizontal pass broadcast taps with input pairs.
+// Works on the raw integer frame difference; the 2^-(bpc-8) sample scale is applied to the final sum
+// (exact: a power of two commutes with every rounding on the way).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void motion_kernel(const MotionArgs a) {
-  __shared__ float sv[TH][P];
+  __shared__ f2 sv[TH / 2][kP2];
   __shared__ double red[4];
   const int tile = xcd_remap(blockIdx.x, a.n_tiles);
   const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
@@ -37,61 +43,73 @@ __global__ __launch_bounds__(kBlock) void motion_kernel(const MotionArgs a) {
   const int tid = threadIdx.x;
   const T* __restrict__ cur = (const T*)a.ref + (int64_t)fr * a.frame_pitch;
   const T* __restrict__ prev;
-  int64_t prev_pitch;
+  unsigned pitch_p;
   if (fr == 0) {
     prev = (const T*)a.prev0;
-    prev_pitch = a.prev0_row_pitch;
+    pitch_p = (unsigned)a.prev0_row_pitch;
   } else {
     prev = cur - a.frame_pitch;
-    prev_pitch = a.row_pitch;
+    pitch_p = (unsigned)a.row_pitch;
   }
   if (prev == nullptr) {  // first frame of the clip: motion_0 = 0
     if (tid == 0) a.partials[(int64_t)fr * a.n_tiles + tile] = 0.0;
     return;
   }
+  const unsigned pitch_c = (unsigned)a.row_pitch;
+  const rsrc_t rsrc_c = make_rsrc(cur, (unsigned)a.h * pitch_c * (unsigned)sizeof(T));
+  const rsrc_t rsrc_p = make_rsrc(prev, (unsigned)a.h * pitch_p * (unsigned)sizeof(T));
   const int x0 = tx * TW, y0 = ty * TH;
   {
-    const int col = tid & 127, seg = tid >> 7;
+    const int col = tid & 127;
+    const int seg = __builtin_amdgcn_readfirstlane(tid >> 7);
     if (col < COLS) {
-      const int gx = mirror(x0 - R + col, a.w);
-      float acc[S];
+      const unsigned gx = (unsigned)mirror1(x0 - R + col, a.w);
+      f2 acc[S / 2];
 #pragma unroll
-      for (int o = 0; o < S; ++o) acc[o] = 0.0f;
+      for (int p = 0; p < S / 2; ++p) acc[p] = f2{0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < NIN; ++j) {
-        const int gy = mirror(y0 + seg * S - R + j, a.h);
-        const float d = (PixIO<T>::raw(cur + (int64_t)gy * a.row_pitch + gx) -
-                         PixIO<T>::raw(prev + (int64_t)gy * prev_pitch + gx)) * a.inv_scale;
+        const unsigned gy = (unsigned)mirror1(y0 + seg * S - R + j, a.h);
+        const int c = (int)buf_load<T>(rsrc_c, gx, gy * pitch_c);
+        const int p0 = (int)buf_load<T>(rsrc_p, gx, gy * pitch_p);
+        const float d = (float)(c - p0);
 #pragma unroll
-        for (int o = 0; o < S; ++o) {
-          const int k = j - o;
-          if (k >= 0 && k < 5) acc[o] = fmaf(a.f[k], d, acc[o]);
+        for (int p = 0; p < S / 2; ++p) {
+          const int k = j - 2 * p;
+          if (k >= 0 && k <= 5) acc[p] = __builtin_elementwise_fma(a.vt[k], f2{d, d}, acc[p]);
         }
       }
 #pragma unroll
-      for (int o = 0; o < S; ++o) sv[seg * S + o][col] = acc[o];
+      for (int p = 0; p < S / 2; ++p) sv[seg * (S / 2) + p][col] = acc[p];
     }
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
-  const int row = lane & 15, seg = wave + 4 * (lane >> 4);
+  const int rp = lane & 7, seg = wave + 4 * (lane >> 3);
   float sad = 0.0f;
   if (seg < NSEG) {
-    float in[12];
-    const float2* p = reinterpret_cast<const float2*>(&sv[row][seg * 8]);
+    f2 in[8];
+    const f4* p = reinterpret_cast<const f4*>(&sv[rp][seg * 4]);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const float2 v = p[q];
-      in[2 * q] = v.x;
-      in[2 * q + 1] = v.y;
+    for (int q = 0; q < 4; ++q) {
+      const f4 v = p[q];
+      in[2 * q] = f2{v.x, v.y};
+      in[2 * q + 1] = f2{v.z, v.w};
     }
-    const int gy = y0 + row;
+    f2 out[4];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      float acc = 0.0f;
+    for (int o = 0; o < 4; ++o) out[o] = f2{0.0f, 0.0f};
 #pragma unroll
-      for (int k = 0; k < 5; ++k) acc = fmaf(a.f[k], in[o + k], acc);
-      if (x0 + seg * 8 + o < a.w && gy < a.h) sad += fabsf(acc);
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) out[o] = __builtin_elementwise_fma(a.ht[k], in[o + k], out[o]);
+    const int gyA = y0 + 2 * rp;
+    const float mA = gyA < a.h ? 1.0f : 0.0f, mB = gyA + 1 < a.h ? 1.0f : 0.0f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float mc = (x0 + seg * 4 + o) < a.w ? 1.0f : 0.0f;
+      sad = fmaf(mc * mA, fabsf(out[o].x), sad);
+      sad = fmaf(mc * mB, fabsf(out[o].y), sad);
     }
   }
   double v[1] = {(double)sad};
@@ -110,12 +128,15 @@ hipError_t launch_motion(hipStream_t stream, Elem elem, PlaneRun ref, const void
   a.w = w; a.h = h;
   a.tiles_x = (w + TW - 1) / TW;
   a.n_tiles = motion_tiles(w, h);
-  a.inv_scale = inv_scale;
+  (void)inv_scale;  // applied by the finalize stage (motion_norm)
   a.partials = partials;
   {  // FILTER_5_s: 5 taps, sigma 1.0
     double v[5], sum = 0.0;
+    float f[5];
     for (int k = 0; k < 5; ++k) { v[k] = exp(-0.5 * (k - 2) * (k - 2)); sum += v[k]; }
-    for (int k = 0; k < 5; ++k) a.f[k] = (float)(v[k] / sum);
+    for (int k = 0; k < 5; ++k) f[k] = (float)(v[k] / sum);
+    for (int k = 0; k <= 5; ++k) a.vt[k] = f2{k < 5 ? f[k] : 0.0f, k > 0 ? f[k - 1] : 0.0f};
+    for (int k = 0; k < 5; ++k) a.ht[k] = f2{f[k], f[k]};
   }
   const dim3 grid(a.n_tiles, n_frames), block(kBlock);
   switch (elem) {

@@ -184,20 +184,24 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     Elem ce = c->elem;
     int cw = w, ch = h;
     for (int s = 0; s < 4; ++s) {
-      if (s > 0) {
-        Level& L = c->vif_lv[s];
-        ProfScope ps(c, 3 + s, sp_n);
-        HIPCHK(c, launch_vif_decimate(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
-                                      MutPlaneRun{L.ref, L.pitch, L.frame_pitch},
-                                      MutPlaneRun{L.dis, L.pitch, L.frame_pitch}));
+      MutPlaneRun nr{nullptr, 0, 0}, nd{nullptr, 0, 0};
+      if (s < 3) {
+        Level& L = c->vif_lv[s + 1];
+        nr = MutPlaneRun{L.ref, L.pitch, L.frame_pitch};
+        nd = MutPlaneRun{L.dis, L.pitch, L.frame_pitch};
+      }
+      {
+        ProfScope ps(c, s, sp_n);
+        HIPCHK(c, launch_vif_stat(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
+                                  (float)c->cfg.vif_enhn_gain_limit, c->vif_part[s], nr, nd));
+      }
+      if (s < 3) {
+        Level& L = c->vif_lv[s + 1];
         cr = PlaneRun{L.ref, L.pitch, L.frame_pitch};
         cd = PlaneRun{L.dis, L.pitch, L.frame_pitch};
         ce = ELEM_F32;
         cw = L.w; ch = L.h;
       }
-      ProfScope ps(c, s, sp_n);
-      HIPCHK(c, launch_vif_stat(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
-                                (float)c->cfg.vif_enhn_gain_limit, c->vif_part[s]));
     }
   }
   if ((feat & PQA_FEAT_ADM) && sp_n > 0) {
@@ -262,7 +266,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     fa.adm_part[s] = c->adm_part[s]; fa.adm_tiles[s] = c->adm_tiles[s]; fa.adm_area[s] = c->adm_area[s];
   }
   fa.motion_part = c->motion_part; fa.motion_tiles = c->motion_tiles_n;
-  fa.motion_norm = 1.0 / ((double)w * h);
+  fa.motion_norm = (double)c->inv_scale / ((double)w * h);
   for (int p = 0; p < 3; ++p) {
     fa.sse_part[p] = c->sse_part[p];
     fa.ssim_part[p] = c->ssim_part[p]; fa.ssim_tiles[p] = c->ssim_tiles_n[p]; fa.ssim_norm[p] = c->ssim_norm[p];

@@ -44,10 +44,13 @@ static Taps gaussian_taps(int n) {
 struct TapPairs {
   f2 vt[18];  // vertical:   {c[k], c[k-1]}
   f2 ht[17];  // horizontal: {c[k], c[k]}  (ready-made SGPR pairs: no splat moves, no op_sel juggling)
+  f2 dt[9];   // next scale's taps {c'[k], c'[k]} for the fused decimation
 };
 
-static TapPairs tap_pairs(const Taps& t, int n) {
+static TapPairs tap_pairs(const Taps& t, int n, const Taps* next, int n_next) {
   TapPairs p{};
+  if (next)
+    for (int k = 0; k < n_next; ++k) p.dt[k] = f2{next->f[k], next->f[k]};
   for (int k = 0; k <= n; ++k) {
     p.vt[k].x = k < n ? t.f[k] : 0.0f;
     p.vt[k].y = k > 0 ? t.f[k - 1] : 0.0f;
@@ -63,6 +66,10 @@ struct VifStatArgs {
   int w, h, tiles_x, n_tiles;
   float inv_scale, gain_limit;
   double* partials;
+  // fused decimation (scale s -> s+1): filtered with the NEXT scale's taps, even samples kept
+  float* dst_ref;
+  float* dst_dis;
+  int64_t dst_row_pitch_r, dst_frame_pitch_r, dst_row_pitch_d, dst_frame_pitch_d;
   TapPairs taps;
 };
 
@@ -73,12 +80,15 @@ constexpr int kP2 = 130;  // LDS row pitch in float2: == 2 (mod 32) -> conflict-
 // Everything hot is therefore arranged as float2 = {row 2p, row 2p+1} of one column:
 //   vertical pass:   acc{2p,2p+1} += {c[k], c[k-1]} * {x, x}     (tap PAIR from SGPRs, input broadcast)
 //   horizontal pass: out{2p,2p+1}[o] += c[k] * in{2p,2p+1}[o+k]  (tap broadcast, input pair from LDS)
-template <typename T, int N, int TW>
+template <typename T, int N, int TW, int ND>
 __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a) {
   constexpr int R = N / 2, TH = kVifTileH, COLS = TW + N - 1, NSEG = TW / 4, S = 8, NIN = S + N - 1;
+  constexpr int RD = ND / 2;  // ND = taps of the next scale's filter (0: last scale, no decimation)
+  static_assert(ND == 0 || RD <= R, "decimation window must sit inside the statistic window");
   static_assert(COLS <= 128 && COLS <= kP2, "tile too wide");
   static_assert(TW % 4 == 0 && NSEG <= 32 && TH == 16, "segment map");
   __shared__ f2 sv[5][TH / 2][kP2];  // [signal][row pair][column] = {row 2p, row 2p+1}
+  __shared__ f2 sd[ND ? TH / 2 : 1][ND ? kP2 : 1];  // decimation: [even row][column] = {ref, dis}
   __shared__ double red[8];
 
   const int tile = xcd_remap(blockIdx.x, a.n_tiles);
@@ -103,6 +113,9 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
       for (int p = 0; p < S / 2; ++p)
 #pragma unroll
         for (int s = 0; s < 5; ++s) acc[p][s] = f2{0.0f, 0.0f};
+      f2 dacc[S / 2];  // next-scale input at the strip's even rows, {ref, dis}
+#pragma unroll
+      for (int q = 0; q < S / 2; ++q) dacc[q] = f2{0.0f, 0.0f};
       // Input rows stream through in groups of G: the loads of group g+1 are in flight while group g is
       // consumed; sched_barrier keeps hipcc from hoisting all 2*NIN loads (and their r*r, d*d, r*d) to
       // the top, which costs ~120 VGPRs and a wave of occupancy.
@@ -135,6 +148,13 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
             const f2 x = PixIO<T>::pair(rc[i], dc[i], a.inv_scale);  // {r, d} - 128 (one v_pk_add / v_pk_fma)
             const f2 xx = x * x;                                      // {r*r, d*d}   (one v_pk_mul)
             const float r = x.x, d = x.y, rr = xx.x, dd = xx.y, rd = x.x * x.y;
+            if (ND) {
+#pragma unroll
+              for (int q = 0; q < S / 2; ++q) {
+                const int kd = j - (2 * q + R - RD);  // even row 2q, tap kd of the next scale's filter
+                if (kd >= 0 && kd < ND) dacc[q] = __builtin_elementwise_fma(a.taps.dt[kd], x, dacc[q]);
+              }
+            }
 #pragma unroll
             for (int p = 0; p < S / 2; ++p) {
               const int k = j - 2 * p;  // row 2p takes tap k, row 2p+1 tap k-1: both sum taps in increasing order
@@ -155,9 +175,31 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
       for (int p = 0; p < S / 2; ++p)
 #pragma unroll
         for (int s = 0; s < 5; ++s) sv[s][seg * (S / 2) + p][col] = acc[p][s];
+      if (ND) {
+#pragma unroll
+        for (int q = 0; q < S / 2; ++q) sd[seg * (S / 2) + q][col] = dacc[q];
+      }
     }
   }
   __syncthreads();
+
+  // ---- 1b. fused decimation: horizontal pass at even columns, written straight to the next scale --
+  if (ND) {
+    const int ox0 = x0 >> 1, oy0 = y0 >> 1, ow = a.w >> 1, oh = a.h >> 1;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const int item = tid + round * kBlock;
+      const int oc = item & 63, orow = item >> 6;  // 64 slots per row, TW/2 of them used
+      const int gx = ox0 + oc, gy = oy0 + orow;
+      if (oc < TW / 2 && gx < ow && gy < oh) {
+        f2 acc = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < ND; ++k) acc = __builtin_elementwise_fma(a.taps.dt[k], sd[orow][2 * oc + (R - RD) + k], acc);
+        a.dst_ref[(int64_t)fr * a.dst_frame_pitch_r + (int64_t)gy * a.dst_row_pitch_r + gx] = acc.x;
+        a.dst_dis[(int64_t)fr * a.dst_frame_pitch_d + (int64_t)gy * a.dst_row_pitch_d + gx] = acc.y;
+      }
+    }
+  }
 
   // ---- 2. horizontal pass + 3. statistic --------------------------------------------------------
   // lane l: row pair l & 7, segment (4 columns) wave + 4 * (l >> 3).  With the 130-float2 pitch the
@@ -311,13 +353,13 @@ __global__ __launch_bounds__(kBlock) void vif_dec_kernel(const VifDecArgs a) {
   }
 }
 
-template <int N, int TW>
+template <int N, int TW, int ND>
 hipError_t launch_stat_n(hipStream_t stream, Elem elem, const VifStatArgs& a, int n_frames) {
   const dim3 grid(a.n_tiles, n_frames), block(kBlock);
   switch (elem) {
-    case ELEM_U8: hipLaunchKernelGGL((vif_stat_kernel<uint8_t, N, TW>), grid, block, 0, stream, a); break;
-    case ELEM_U16: hipLaunchKernelGGL((vif_stat_kernel<uint16_t, N, TW>), grid, block, 0, stream, a); break;
-    case ELEM_F32: hipLaunchKernelGGL((vif_stat_kernel<float, N, TW>), grid, block, 0, stream, a); break;
+    case ELEM_U8: hipLaunchKernelGGL((vif_stat_kernel<uint8_t, N, TW, ND>), grid, block, 0, stream, a); break;
+    case ELEM_U16: hipLaunchKernelGGL((vif_stat_kernel<uint16_t, N, TW, ND>), grid, block, 0, stream, a); break;
+    case ELEM_F32: hipLaunchKernelGGL((vif_stat_kernel<float, N, TW, ND>), grid, block, 0, stream, a); break;
   }
   return hipGetLastError();
 }
@@ -341,7 +383,8 @@ constexpr int kVifTW[4] = {112, 120, 124, 124};
 int vif_tile_w(int scale) { return kVifTW[scale]; }
 
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
-                           int w, int h, float inv_scale, float gain_limit, double* partials) {
+                           int w, int h, float inv_scale, float gain_limit, double* partials,
+                           MutPlaneRun next_ref, MutPlaneRun next_dis) {
   if (n_frames <= 0) return hipSuccess;
   VifStatArgs a{};
   a.ref = ref.base; a.dis = dis.base;
@@ -352,12 +395,18 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
   a.n_tiles = a.tiles_x * vif_tiles_y(h);
   a.inv_scale = inv_scale; a.gain_limit = gain_limit;
   a.partials = partials;
-  a.taps = tap_pairs(gaussian_taps(kVifN[scale]), kVifN[scale]);
+  a.dst_ref = (float*)next_ref.base; a.dst_dis = (float*)next_dis.base;
+  a.dst_row_pitch_r = next_ref.row_pitch; a.dst_frame_pitch_r = next_ref.frame_pitch;
+  a.dst_row_pitch_d = next_dis.row_pitch; a.dst_frame_pitch_d = next_dis.frame_pitch;
+  const Taps cur = gaussian_taps(kVifN[scale]);
+  const Taps nxt = scale < 3 ? gaussian_taps(kVifN[scale + 1]) : Taps{};
+  a.taps = tap_pairs(cur, kVifN[scale], scale < 3 ? &nxt : nullptr, scale < 3 ? kVifN[scale + 1] : 0);
+  if (scale < 3 && (!a.dst_ref || !a.dst_dis)) return hipErrorInvalidValue;
   switch (scale) {
-    case 0: return launch_stat_n<17, 112>(stream, elem, a, n_frames);
-    case 1: return launch_stat_n<9, 120>(stream, elem, a, n_frames);
-    case 2: return launch_stat_n<5, 124>(stream, elem, a, n_frames);
-    case 3: return launch_stat_n<3, 124>(stream, elem, a, n_frames);
+    case 0: return launch_stat_n<17, 112, 9>(stream, elem, a, n_frames);
+    case 1: return launch_stat_n<9, 120, 5>(stream, elem, a, n_frames);
+    case 2: return launch_stat_n<5, 124, 3>(stream, elem, a, n_frames);
+    case 3: return launch_stat_n<3, 124, 0>(stream, elem, a, n_frames);
   }
   return hipErrorInvalidValue;
 }
