@@ -151,7 +151,9 @@ PQA_API const char* pqa_last_error(const pqa_ctx* ctx);
 
 /* Measurement hooks (bench.py): HIP-event timing of individual kernels on the context's stream.
  * kernel ids: 0..3 vif_stat scale s, 4..6 vif_decimate to scale 1..3, 7..10 adm scale s,
- * 11 motion, 12 sse, 13 ssim, 14 finalize. */
+ * 11 motion, 12 sse, 13 ssim, 14 finalize.
+ * pqa_profile_enable(ctx, 0) stops, (ctx, 1) times every kernel, (ctx, mask << 1) only the kernels whose bit
+ * is set in mask (event records between kernels are not free: ~10 % of a step when every kernel is timed). */
 enum { PQA_PROF_KERNELS = 15 };
 PQA_API int pqa_profile_enable(pqa_ctx* ctx, int on);
 PQA_API int pqa_profile_read(pqa_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches, uint64_t* frames);

@@ -36,11 +36,12 @@ struct AdmArgs {
 };
 
 constexpr int TW = kAdmTileW, TH = kAdmTileH, GW = TW + 2, GH = TH + 2;
-constexpr int VC = 2 * GW + 2, VP = 136;  // vertical-pass columns / LDS pitch (float2)
+constexpr int VC = 2 * GW + 2, VP = 128;  // vertical-pass columns (126) / LDS pitch (float2)
+static_assert(VC <= 128 && VC <= VP, "one column per lane, two strips per workgroup");
 constexpr int SROWS = GH / 2;             // output rows per vertical strip (2 strips)
 constexpr int NIN = 2 * SROWS + 2;        // input rows per strip
 constexpr int NROUND = 5;                 // phase 2/3 rounds: 4.5 x (64 cols x 4 rows) + halo columns
-constexpr int GP = GW + 1;                // pitch of the masking-signal array
+constexpr int GP = GW + 3;                // pitch of the masking-signal array
 
 __device__ __forceinline__ f2 splat(float c) { return f2{c, c}; }
 
@@ -68,30 +69,18 @@ __global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
   const rsrc_t rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d * (unsigned)sizeof(T));
 
   // ---- phase 1: vertical DWT -------------------------------------------------------------------
-  // items: 128 columns x 2 strips in round 0, the last VC-128 columns x 2 strips in round 1 (wave 0 only)
-  for (int round = 0; round < 2; ++round) {
-    int col, strip;
-    if (round == 0) {
-      col = tid & 127;
-      strip = __builtin_amdgcn_readfirstlane(tid >> 7);
-    } else {
-      if (tid >= 2 * (VC - 128)) break;
-      col = 128 + (tid >> 1);
-      strip = tid & 1;
-    }
+  // items: VC (126) columns x 2 strips of 9 output rows: one pass, every wave busy, rows wave-uniform
+  {
+    const int col = tid & 127;
+    const int strip = __builtin_amdgcn_readfirstlane(tid >> 7);
+    if (col < VC) {
     const unsigned gx = (unsigned)mirror1(2 * cx0 - 3 + col, a.w);
     f2 x[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
       const unsigned gy = (unsigned)mirror1(2 * cy0 - 3 + 2 * SROWS * strip + j, a.h);
-      T r, d;
-      if (round == 0) {  // strip is wave-uniform: the row offset rides in an SGPR
-        r = buf_load<T>(rsrc_r, gx, gy * pitch_r);
-        d = buf_load<T>(rsrc_d, gx, gy * pitch_d);
-      } else {           // 12 stragglers with per-lane strips: everything in the lane offset
-        r = buf_load<T>(rsrc_r, gx + gy * pitch_r, 0u);
-        d = buf_load<T>(rsrc_d, gx + gy * pitch_d, 0u);
-      }
+      const T r = buf_load<T>(rsrc_r, gx, gy * pitch_r);  // row offset rides in an SGPR
+      const T d = buf_load<T>(rsrc_d, gx, gy * pitch_d);
       x[j] = PixIO<T>::pair(r, d, a.inv_scale);
     }
 #pragma unroll
@@ -107,6 +96,7 @@ __global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
       vh = __builtin_elementwise_fma(splat(hi3), x[2 * o + 3], vh);
       Vlo[lr][col] = vl;
       Vhi[lr][col] = vh;
+    }
     }
   }
   __syncthreads();
@@ -126,9 +116,11 @@ __global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
     if (k < 4) {
       lcx = 1 + (tid & 63);
       lcy = 4 * k + (tid >> 6);
+      have = lcx <= TW;
     } else if (tid < 128) {
       lcx = 1 + (tid & 63);
       lcy = 16 + (tid >> 6);
+      have = lcx <= TW;
     } else {
       const int t = tid - 128;
       have = t < 2 * GH;
@@ -239,8 +231,9 @@ __global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
     num_v += xv * xv * xv;
     num_d += xd * xd * xd;
   }
-  double v[6] = {(double)num_h, (double)num_v, (double)num_d, (double)den_h, (double)den_v, (double)den_d};
-  block_sum<6>(v, red);
+  const float part[6] = {num_h, num_v, num_d, den_h, den_v, den_d};
+  double v[6];
+  block_sum_f32<6>(part, v, red);
   if (tid == 0) {
     double* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * 6;
 #pragma unroll

@@ -43,7 +43,7 @@ hipError_t launch_vif_decimate(hipStream_t stream, int dst_scale, Elem elem, Pla
                                MutPlaneRun dst_dis);
 
 // ---- ADM ------------------------------------------------------------------------------------
-constexpr int kAdmTileW = 64, kAdmTileH = 16;
+constexpr int kAdmTileW = 60, kAdmTileH = 16;  // 2*(60+2)+2 = 126 input columns: one per lane
 inline int adm_tiles_x(int band_w) { return (band_w + kAdmTileW - 1) / kAdmTileW; }
 inline int adm_tiles_y(int band_h) { return (band_h + kAdmTileH - 1) / kAdmTileH; }
 

@@ -112,8 +112,9 @@ __global__ __launch_bounds__(kBlock) void motion_kernel(const MotionArgs a) {
       sad = fmaf(mc * mB, fabsf(out[o].y), sad);
     }
   }
-  double v[1] = {(double)sad};
-  block_sum<1>(v, red);
+  const float part[1] = {sad};
+  double v[1];
+  block_sum_f32<1>(part, v, red);
   if (tid == 0) a.partials[(int64_t)fr * a.n_tiles + tile] = v[0];
 }
 

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -42,6 +43,8 @@ struct pqa_ctx {
   pqa_config cfg{};
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+  hipStream_t aux[2] = {nullptr, nullptr};  // ADM and motion/PSNR/SSIM chains run beside the VIF chain
+  hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
   Elem elem = ELEM_U8;
   int esize = 1;
   float inv_scale = 1.0f;
@@ -78,7 +81,9 @@ struct pqa_ctx {
   std::string err;
   std::vector<void*> allocs;
   // profiling
+  bool multi_stream = false;
   bool prof = false;
+  uint32_t prof_mask = 0xffffffffu;
   std::vector<ProfEv> evs;
   double prof_ms[PQA_PROF_KERNELS] = {};
   uint64_t prof_n[PQA_PROF_KERNELS] = {}, prof_frames[PQA_PROF_KERNELS] = {};
@@ -125,15 +130,17 @@ struct ProfScope {
   pqa_ctx* c;
   ProfEv ev{};
   bool on;
-  ProfScope(pqa_ctx* ctx, int id, int frames) : c(ctx), on(ctx->prof) {
+  hipStream_t st;
+  ProfScope(pqa_ctx* ctx, int id, int frames, hipStream_t stream)
+      : c(ctx), on(ctx->prof && ((ctx->prof_mask >> id) & 1u)), st(stream) {
     if (!on) return;
     ev.id = id; ev.frames = frames;
     if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
-    hipEventRecord(ev.a, c->stream);
+    hipEventRecord(ev.a, st);
   }
   ~ProfScope() {
     if (!on) return;
-    hipEventRecord(ev.b, c->stream);
+    hipEventRecord(ev.b, st);
     c->evs.push_back(ev);
   }
 };
@@ -166,6 +173,16 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   const PlaneRun dY{dis->plane[0], dis->row_pitch[0] / es, dis->frame_pitch[0] / es};
   const int w = c->pw[0], h = c->ph[0];
   hipStream_t st = c->stream;
+  // fork: the ADM chain and the motion/PSNR/SSIM kernels are independent of the VIF chain; on their own
+  // streams they fill the SIMD time the VALU-bound VIF kernels leave while waiting, and the small deep-scale
+  // grids overlap instead of running one after another
+  const bool multi = c->multi_stream;
+  hipStream_t st_adm = multi ? c->aux[0] : st, st_misc = multi ? c->aux[1] : st;
+  if (multi) {
+    HIPCHK(c, hipEventRecord(c->fork_ev, st));
+    HIPCHK(c, hipStreamWaitEvent(st_adm, c->fork_ev, 0));
+    HIPCHK(c, hipStreamWaitEvent(st_misc, c->fork_ev, 0));
+  }
 
   // frames that get spatial features (libvmaf n_subsample: index % k == 0)
   const int k = c->k_sub;
@@ -191,7 +208,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
         nd = MutPlaneRun{L.dis, L.pitch, L.frame_pitch};
       }
       {
-        ProfScope ps(c, s, sp_n);
+        ProfScope ps(c, s, sp_n, st);
         HIPCHK(c, launch_vif_stat(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
                                   (float)c->cfg.vif_enhn_gain_limit, c->vif_part[s], nr, nd));
       }
@@ -216,8 +233,8 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
         ld = MutPlaneRun{L.dis, L.pitch, L.frame_pitch};
       }
       {
-        ProfScope ps(c, 7 + s, sp_n);
-        HIPCHK(c, launch_adm_scale(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
+        ProfScope ps(c, 7 + s, sp_n, st_adm);
+        HIPCHK(c, launch_adm_scale(st_adm, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
                                    (float)c->cfg.adm_enhn_gain_limit, lr, ld, c->adm_part[s]));
       }
       if (s < 3) {
@@ -237,27 +254,34 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       p0_pitch = c->last_luma_pitch;
     }
     if (p0 && p0_pitch % es) return fail(c, PQA_EINVAL, "halo pitch is not a multiple of the sample size");
-    ProfScope ps(c, 11, n);
-    HIPCHK(c, launch_motion(st, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h, c->inv_scale, c->motion_part));
+    ProfScope ps(c, 11, n, st_misc);
+    HIPCHK(c, launch_motion(st_misc, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h, c->inv_scale, c->motion_part));
   }
   int n_sse = 0, n_ssim = 0;
   if (feat & PQA_FEAT_PSNR) {
     n_sse = c->n_planes;
-    ProfScope ps(c, 12, n);
+    ProfScope ps(c, 12, n, st_misc);
     for (int p = 0; p < c->n_planes; ++p) {
       const PlaneRun a{dis->plane[p], dis->row_pitch[p] / es, dis->frame_pitch[p] / es};
       const PlaneRun b{ref->plane[p], ref->row_pitch[p] / es, ref->frame_pitch[p] / es};
-      HIPCHK(c, launch_sse(st, c->elem, a, b, n, c->pw[p], c->ph[p], c->sse_part[p]));
+      HIPCHK(c, launch_sse(st_misc, c->elem, a, b, n, c->pw[p], c->ph[p], c->sse_part[p]));
     }
   }
   if (feat & PQA_FEAT_SSIM) {
     n_ssim = c->n_planes;
-    ProfScope ps(c, 13, n);
+    ProfScope ps(c, 13, n, st_misc);
     for (int p = 0; p < c->n_planes; ++p) {
       const PlaneRun a{dis->plane[p], dis->row_pitch[p] / es, dis->frame_pitch[p] / es};
       const PlaneRun b{ref->plane[p], ref->row_pitch[p] / es, ref->frame_pitch[p] / es};
-      HIPCHK(c, launch_ssim(st, c->elem, a, b, n, c->pw[p], c->ph[p], (1 << c->cfg.bit_depth) - 1, c->ssim_part[p]));
+      HIPCHK(c, launch_ssim(st_misc, c->elem, a, b, n, c->pw[p], c->ph[p], (1 << c->cfg.bit_depth) - 1, c->ssim_part[p]));
     }
+  }
+
+  if (multi) {  // join
+    HIPCHK(c, hipEventRecord(c->join_ev[0], st_adm));
+    HIPCHK(c, hipEventRecord(c->join_ev[1], st_misc));
+    HIPCHK(c, hipStreamWaitEvent(st, c->join_ev[0], 0));
+    HIPCHK(c, hipStreamWaitEvent(st, c->join_ev[1], 0));
   }
 
   FinalizeArgs fa{};
@@ -275,7 +299,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   fa.record_stride = PQA_RECORD_DOUBLES;
   fa.capacity = c->capacity;
   {
-    ProfScope ps(c, 14, n);
+    ProfScope ps(c, 14, n, st);
     if (k > 1) {
       if (sp_n > 0 && (feat & (PQA_FEAT_VIF | PQA_FEAT_ADM))) {
         FinalizeArgs f1 = fa;
@@ -437,6 +461,15 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   CREATE_HIP(hipSetDevice(c->device));
   CREATE_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
+  {
+    const char* e = getenv("PQA_MULTI_STREAM");  // experiment switch: overlap the VIF / ADM / motion chains
+    c->multi_stream = e && e[0] == '1';
+  }
+  for (int i = 0; i < 2; ++i) {
+    CREATE_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+    CREATE_HIP(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
+  }
+  CREATE_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
 
   const int w = c->pw[0], h = c->ph[0], B = c->B;
   // VIF pyramid (floor halving) and ADM approximation bands (ceil halving), f32, rows padded to 64 B
@@ -496,6 +529,7 @@ void pqa_destroy(pqa_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+  for (int i = 0; i < 2; ++i) if (c->aux[i]) hipStreamSynchronize(c->aux[i]);
   prof_drain(c);
   for (void* p : c->allocs) hipFree(p);
   for (int i = 0; i < 2; ++i) {
@@ -506,6 +540,11 @@ void pqa_destroy(pqa_ctx* c) {
     if (H.computed) hipEventDestroy(H.computed);
   }
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  for (int i = 0; i < 2; ++i) {
+    if (c->aux[i]) hipStreamDestroy(c->aux[i]);
+    if (c->join_ev[i]) hipEventDestroy(c->join_ev[i]);
+  }
+  if (c->fork_ev) hipEventDestroy(c->fork_ev);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -674,6 +713,7 @@ int pqa_profile_enable(pqa_ctx* c, int on) {
   if (!c) return PQA_EINVAL;
   prof_drain(c);
   c->prof = on != 0;
+  c->prof_mask = (on == 1 || on == 0) ? 0xffffffffu : (uint32_t)on >> 1;  // on = 1: all; on = (mask << 1): subset
   if (on) {
     memset(c->prof_ms, 0, sizeof c->prof_ms);
     memset(c->prof_n, 0, sizeof c->prof_n);

@@ -105,6 +105,40 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [4*NV]
   }
 }
 
+// Wave64 sum of one float per lane with DPP adds only (no LDS traffic, 6 VALU): quad swaps, row shifts,
+// then row broadcasts; the total lands in lane 63 and is returned wave-uniform.  Fixed order: deterministic.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v = dpp_add<0xb1>(v);         // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e>(v);         // quad_perm:[2,3,0,1]
+  v = dpp_add<0x114>(v);        // row_shr:4
+  v = dpp_add<0x118>(v);        // row_shr:8   -> lane 15 of each row holds the row sum
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Block sum of NV floats per thread: DPP inside each wave (f32), the four wave totals added in double
+// by thread 0.  Result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void block_sum_f32(const float (&in)[NV], double (&out)[NV], double* lds /* [4*NV] */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float w = wave_sum_f32(in[i]);
+    if (lane == 0) lds[wid * NV + i] = (double)w;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) out[i] = (lds[i] + lds[NV + i]) + (lds[2 * NV + i] + lds[3 * NV + i]);
+  }
+}
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32 (base 2)
 

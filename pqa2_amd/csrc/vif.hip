@@ -269,8 +269,9 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
       __builtin_amdgcn_sched_barrier(0);  // two pixels' worth of temporaries live at a time
     }
   }
-  double v[2] = {(double)num, (double)den};
-  block_sum<2>(v, red);
+  const float part[2] = {num, den};
+  double v[2];
+  block_sum_f32<2>(part, v, red);
   if (tid == 0) {
     double* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * 2;
     out[0] = v[0];

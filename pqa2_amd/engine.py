@@ -117,8 +117,19 @@ class FeatureEngine:
         self._check(self.lib.pqa_reset(self._ctx))
 
     # -- measurement ---------------------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
-        self._check(self.lib.pqa_profile_enable(self._ctx, 1 if on else 0))
+    def profile_enable(self, on=True):
+        """True: time every kernel; False: stop; an iterable of kernel ids: time only those (event records
+        between kernels are not free, so the bench times just the dominant kernel inside its timed region)."""
+        if on is True:
+            code = 1
+        elif not on:
+            code = 0
+        else:
+            mask = 0
+            for k in on:
+                mask |= 1 << int(k)
+            code = mask << 1
+        self._check(self.lib.pqa_profile_enable(self._ctx, code))
 
     def profile_read(self) -> dict:
         out = {}
