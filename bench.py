@@ -46,8 +46,12 @@ def main():
     ap.add_argument("--frames", type=int, default=300, help="frames per rank")
     ap.add_argument("--batch", type=int, default=16, help="frames per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=2)
+    ap.add_argument("--cpu-sample-frames", type=int, default=0, help="0: sized for ~12 s of CPU work")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(16, host cores) -- the 1-GPU share of the box")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-device rehearses the N>1 path on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -67,10 +71,16 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the scoring path has no CPU fallback)", file=sys.stderr)
         sys.exit(3)
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    gather_dev = dev if args.backend == "nccl" else None
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     w, h, bpc, model_name, side = WORKLOADS[args.workload]
     F = args.frames
@@ -103,7 +113,7 @@ def main():
         eng.reset()
         eng.submit_resident(a, F, ref_ptrs, dis_ptrs, row_pitch, frame_pitch, halo_ptr, row_pitch[0])
         rec = eng.collect(a, F)
-        full = shard.gather_records(rec, total, world, rank, dev)
+        full = shard.gather_records(rec, total, world, rank, gather_dev)
         if rank == 0:
             metrics = M.metrics_from_records(full, w, h, prefix)
             scored = M.score_frames(model, metrics)
@@ -134,7 +144,7 @@ def main():
         breakdown = eng.profile_read()
         eng.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev if gather_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -167,10 +177,12 @@ def main():
                                "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"]}
             out["kernel_ms_per_frame"] = {name: round(v["ms"] / max(1, v["frames"]), 5)
                                           for name, v in breakdown.items() if v["launches"]}
-            out["kernel_ms_note"] = "separate untimed pass with every kernel event-timed; chains overlap on 3 streams"
+            out["kernel_ms_note"] = "from one extra untimed pass with every kernel event-timed (ms per frame)"
 
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, args.cpu_sample_frames,
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            n_sample = args.cpu_sample_frames or max(2, min(F, threads * max(1, int(12.0 / (w * h * 2.0e-7)))))
+            out["cpu_baseline"] = _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads,
                                                 result["records"], model, prefix)
         print(json.dumps(out), flush=True)
     eng.close()
@@ -189,9 +201,9 @@ def _traffic_from_profiles(workload: str):
         return None
 
 
-def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, gpu_records, model, prefix):
-    """Time the CPU oracle (scalar C port of the libvmaf float extractors, 1 thread) on the first
-    `n_sample` frames of the very same clip, and report how far the GPU records are from it."""
+def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads, gpu_records, model, prefix):
+    """Time the CPU oracle (scalar C port of the libvmaf float extractors, one frame per thread) on the
+    first `n_sample` frames of the very same clip, and report how far the GPU records are from it."""
     from oracle.oracle import Oracle
     from pqa2_amd import model as M
     orc = Oracle("f32")
@@ -201,8 +213,8 @@ def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, gpu_records, model, p
         refs = [r.view(np.uint16) for r in refs]
         diss = [d.view(np.uint16) for d in diss]
     t0 = time.perf_counter()
-    exp = orc.clip_features(refs, diss, bpc, vif_gain_limit=model.vif_enhn_gain_limit,
-                            adm_gain_limit=model.adm_enhn_gain_limit)
+    exp = orc.clip_features_mt(refs, diss, bpc, threads, vif_gain_limit=model.vif_enhn_gain_limit,
+                               adm_gain_limit=model.adm_enhn_gain_limit)
     dt = time.perf_counter() - t0
     got = gpu_records[:n_sample, :17]
     rel = np.abs(got[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-12)
@@ -210,9 +222,10 @@ def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, gpu_records, model, p
     rec[:, :17] = exp
     v_cpu = M.score_frames(model, M.metrics_from_records(rec, w, h, prefix))["vmaf"]
     v_gpu = M.score_frames(model, M.metrics_from_records(gpu_records[:n_sample], w, h, prefix))["vmaf"]
-    return {"value": round(n_sample / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": round(n_sample / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"first {n_sample} frames of the same clip, oracle/vmaf_oracle.c f32 (VIF+ADM+motion), "
-                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores; ffmpeg/libvmaf not present on this box",
+                      f"{dt:.1f} s on {threads} threads (one frame each) of {os.cpu_count()} host cores; "
+                      f"ffmpeg/libvmaf not present on this box",
             "gpu_vs_oracle_max_rel_feature_err": float(rel.max()),
             "gpu_vs_oracle_max_abs_vmaf_err": float(np.abs(v_cpu - v_gpu).max())}
 

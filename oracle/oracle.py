@@ -109,6 +109,21 @@ class Oracle:
             out.append(f)
         return np.stack(out) if out else np.zeros((0, N_FEAT))
 
+    def clip_features_mt(self, ref_frames, dis_frames, bpc: int = 8, threads: int = 4,
+                         vif_gain_limit: float = 100.0, adm_gain_limit: float = 100.0) -> np.ndarray:
+        """clip_features on a thread pool (ctypes releases the GIL): frame i is independent once it blurs
+        reference frame i-1 itself.  Same numbers as clip_features."""
+        from concurrent.futures import ThreadPoolExecutor
+        n = len(ref_frames)
+
+        def one(i):
+            prev_blur = self._blur_only(ref_frames[i - 1], bpc)[1] if i > 0 else None
+            return self.frame_features(ref_frames[i], dis_frames[i], bpc, prev_blur, vif_gain_limit, adm_gain_limit)[0]
+
+        with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+            out = list(ex.map(one, range(n)))
+        return np.stack(out) if out else np.zeros((0, N_FEAT))
+
     def _blur_only(self, ref_y: np.ndarray, bpc: int):
         ref = self.picture_copy(ref_y, bpc)
         blur = np.empty_like(ref)
