@@ -26,7 +26,7 @@ struct MutPlaneRun {
 // ---- VIF ------------------------------------------------------------------------------------
 // Tile geometry of the statistic kernel at a scale (filter widths 17/9/5/3).
 int vif_tile_w(int scale);
-constexpr int kVifTileH = 16;
+constexpr int kVifTileH = 8;
 inline int vif_tiles_x(int scale, int w) { return (w + vif_tile_w(scale) - 1) / vif_tile_w(scale); }
 inline int vif_tiles_y(int h) { return (h + kVifTileH - 1) / kVifTileH; }
 

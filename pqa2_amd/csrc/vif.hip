@@ -4,16 +4,18 @@
 // vif_filter1d_sq_s / vif_filter1d_xy_s / vif_dec2_s / vif_statistic_s) -- the code behind the
 // reference's `libvmaf=` call site, app/vmaf_analyzer.py:373-419 -- restated in oracle/vmaf_oracle.c.
 //
-// Kernel shape (one workgroup = 4 waves = one TW x 16 output tile of one frame):
-//   1. vertical pass: lane <-> column.  Each thread streams NIN = 8+N-1 input rows of its column
-//      straight from HBM/L2 (coalesced row segments, no re-layout), forms r, d, r*r, d*d, r*d and
-//      scatters them into 8 x 5 register accumulators in libvmaf's tap order; results go to LDS.
-//   2. horizontal pass: lane <-> (row, 8-column segment).  ds_read_b64 with a pitch of 130 floats and
-//      segments dealt 4 apart per 16-lane group => conflict-free (bank = 2*row + 32*group).
-//      8 x 5 outputs per thread stay in registers and feed the statistic directly.
-//   3. statistic + wave-shuffle / LDS block reduction in double -> one (num, den) partial per tile;
-//      a fixed-order second stage (finalize.hip) makes 1..8-GPU results bit-identical.
-// Nothing but the two partial doubles is written: HBM traffic = the two input planes, once.
+// Kernel shape (one workgroup = 4 waves = one TW x 8 output tile of one frame, TW = 240/248/252):
+//   1. vertical pass: thread <-> column (TW + N - 1 <= 256 columns).  Each thread streams its column's
+//      8 + N - 1 input rows with buffer loads whose row offset is an SGPR (coalesced row segments, zero
+//      VALU address math), forms r, d, r*r, d*d, r*d and accumulates 4 row PAIRS x 5 signals with
+//      v_pk_fma_f32: acc{2p,2p+1} += {c[k], c[k-1]} * {x, x} (tap pair from SGPRs, input broadcast), in
+//      libvmaf's tap order.  The next scale's input (filter with the next kernel, keep even samples) is
+//      accumulated from the same rows.  Results go to LDS as float2 = {row 2p, row 2p+1}.
+//   2. horizontal pass: lane <-> (row pair, 4-column segment); ds_read_b128 of input pairs, conflict-free
+//      by construction (see the lane map below); out{2p,2p+1}[o] += c[k] * in{2p,2p+1}[o+k].
+//   3. statistic on the pair, DPP wave sum, one (num, den) double partial per tile; a fixed-order second
+//      stage (finalize.hip) makes 1..8-GPU results bit-identical.
+// HBM traffic: the two input planes once (halo re-reads hit L2) + the half-resolution planes written once.
 #include "kernels.h"
 #include "pqa_device.h"
 
@@ -73,7 +75,7 @@ struct VifStatArgs {
   TapPairs taps;
 };
 
-constexpr int kP2 = 130;  // LDS row pitch in float2: == 2 (mod 32) -> conflict-free ds_read_b128 (see below)
+constexpr int kP2 = 258;  // LDS row pitch in float2: == 2 (mod 32) -> conflict-free ds_read_b128 (see below)
 
 // FP32 on gfx950 issues one wave64 VALU instruction per 4 cycles per SIMD; v_pk_fma_f32 does two FMAs
 // in that slot (measured: 74 TFLOP/s with v_fma_f32, 132-137 with v_pk_fma_f32, tools/ubench/fma_rate.hip).
@@ -85,8 +87,8 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
   constexpr int R = N / 2, TH = kVifTileH, COLS = TW + N - 1, NSEG = TW / 4, S = 8, NIN = S + N - 1;
   constexpr int RD = ND / 2;  // ND = taps of the next scale's filter (0: last scale, no decimation)
   static_assert(ND == 0 || RD <= R, "decimation window must sit inside the statistic window");
-  static_assert(COLS <= 128 && COLS <= kP2, "tile too wide");
-  static_assert(TW % 4 == 0 && NSEG <= 32 && TH == 16, "segment map");
+  static_assert(COLS <= 256 && COLS <= kP2, "one column per thread");
+  static_assert(TW % 4 == 0 && NSEG <= 64 && TH == S, "segment map");
   __shared__ f2 sv[5][TH / 2][kP2];  // [signal][row pair][column] = {row 2p, row 2p+1}
   __shared__ f2 sd[ND ? TH / 2 : 1][ND ? kP2 : 1];  // decimation: [even row][column] = {ref, dis}
   __shared__ double red[8];
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
 
   // ---- 1. vertical pass: lane <-> column, wave-uniform row addressing ---------------------------
   {
-    const int col = tid & 127;
-    const int seg = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform: rows stay in SGPRs
+    const int col = tid;   // one column per thread; the 8-row strip is the whole tile: rows are uniform
+    constexpr int seg = 0;
     if (col < COLS) {
       const unsigned gx = (unsigned)mirror1(x0 - R + col, a.w);
       const unsigned pitch_r = (unsigned)a.row_pitch_r, pitch_d = (unsigned)a.row_pitch_d;  // planes < 4 G samples
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
       const int item = tid + round * kBlock;
-      const int oc = item & 63, orow = item >> 6;  // 64 slots per row, TW/2 of them used
+      const int oc = item & 127, orow = item >> 7;  // 128 slots per row, TW/2 of them used
       const int gx = ox0 + oc, gy = oy0 + orow;
       if (oc < TW / 2 && gx < ow && gy < oh) {
         f2 acc = f2{0.0f, 0.0f};
@@ -202,11 +204,13 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
   }
 
   // ---- 2. horizontal pass + 3. statistic --------------------------------------------------------
-  // lane l: row pair l & 7, segment (4 columns) wave + 4 * (l >> 3).  With the 130-float2 pitch the
-  // 16-B chunk index of a lane is (rp + 8 * (j & 1) + const) mod 16: distinct inside every ds_read_b128
-  // lane group, i.e. conflict-free.
+  // lane l: row pair rp = l & 3, segment (4 columns) seg = 2*(s&3) + (wave&1) + 8*(s>>2) + 32*(wave>>1)
+  // with s = l >> 2.  The row-pair pitch is 129 16-byte chunks (== 1 mod 16) and 2*seg == 4*s + const
+  // (mod 16), so a lane's chunk index is l + const (mod 16): consecutive lanes hit consecutive chunks,
+  // which is conflict-free for every ds_read_b128 lane group.
   const int wave = tid >> 6, lane = tid & 63;
-  const int rp = lane & 7, seg = wave + 4 * (lane >> 3);
+  const int rp = lane & 3, sl = lane >> 2;
+  const int seg = 2 * (sl & 3) + (wave & 1) + 8 * (sl >> 2) + 32 * (wave >> 1);
   float num = 0.0f, den = 0.0f;
   if (seg < NSEG) {
     constexpr int NCOL = 4 + N - 1, NREAD = (NCOL + 1) / 2;
@@ -236,38 +240,49 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
     // out-of-image positions of edge tiles still hold finite values (mirrored real pixels)
     const int gyA = y0 + 2 * rp;
     const float mrow[2] = {gyA < a.h ? 1.0f : 0.0f, gyA + 1 < a.h ? 1.0f : 0.0f};
+    f2 num2 = f2{0.0f, 0.0f}, den2 = f2{0.0f, 0.0f};
+    const f2 mrow2 = f2{mrow[0], mrow[1]};
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const float mcol = (x0 + seg * 4 + o) < a.w ? 1.0f : 0.0f;
+      // the two rows of the pair go through the statistic together: every add / mul / fma is packed,
+      // only max / min / select / rcp / log are per element
       const f2 mu1 = out[0][o], mu2 = out[1][o];
-      const f2 s1v = out[2][o] - mu1 * mu1, s2v = out[3][o] - mu2 * mu2, s12v = out[4][o] - mu1 * mu2;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float sigma1_sq = fmaxf(s1v[e], 0.0f);
-        const float sigma2_sq = fmaxf(s2v[e], 0.0f);
-        const float sigma12 = s12v[e];
-        // g = sigma12 / (sigma1_sq + eps): v_rcp_f32 plus one Newton correction -- exact 1.0 when the two
-        // are equal (identical frames), 2 FMAs instead of a full IEEE division
-        const float gden = sigma1_sq + eps, grcp = fast_rcp(gden);
-        float g = sigma12 * grcp;
-        g = fmaf(fmaf(-g, gden, sigma12), grcp, g);
-        float sv_sq = sigma2_sq - g * sigma12;
-        // vif_statistic_s also has `if (sigma1_sq < eps) {g = 0; sv_sq = sigma2_sq; sigma1_sq = 0}` and
-        // `if (g < 0) {sv_sq = sigma2_sq; g = 0}`.  Both are dead for the result: the first implies
-        // sigma1_sq < sigma_nsq and the second implies sigma12 < 0, and each of those overrides num/den below.
-        if (sigma2_sq < eps) { g = 0.0f; sv_sq = 0.0f; }
-        sv_sq = fmaxf(sv_sq, eps);
-        g = fminf(g, a.gain_limit);
-        float num_val = fast_log2(1.0f + (g * g * sigma1_sq) * fast_rcp(sv_sq + sigma_nsq));
-        float den_val = fast_log2(1.0f + sigma1_sq * (1.0f / sigma_nsq));
-        if (sigma12 < 0.0f) num_val = 0.0f;
-        if (sigma1_sq < sigma_nsq) { num_val = 1.0f - sigma2_sq * sigma_max_inv; den_val = 1.0f; }
-        const float m = mcol * mrow[e];
-        num = fmaf(m, num_val, num);
-        den = fmaf(m, den_val, den);
-      }
+      f2 s1 = out[2][o] - mu1 * mu1, s2 = out[3][o] - mu2 * mu2;
+      const f2 s12 = out[4][o] - mu1 * mu2;
+      s1 = f2{fmaxf(s1.x, 0.0f), fmaxf(s1.y, 0.0f)};
+      s2 = f2{fmaxf(s2.x, 0.0f), fmaxf(s2.y, 0.0f)};
+      // g = sigma12 / (sigma1_sq + eps): v_rcp_f32 plus one Newton correction -- exact 1.0 when the two
+      // are equal (identical frames), 2 FMAs instead of a full IEEE division
+      const f2 gden = s1 + f2{eps, eps};
+      const f2 grcp = f2{fast_rcp(gden.x), fast_rcp(gden.y)};
+      f2 g = s12 * grcp;
+      g = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, gden, s12), grcp, g);
+      f2 sv = s2 - g * s12;
+      // vif_statistic_s also has `if (sigma1_sq < eps) {g = 0; sv_sq = sigma2_sq; sigma1_sq = 0}` and
+      // `if (g < 0) {sv_sq = sigma2_sq; g = 0}`.  Both are dead for the result: the first implies
+      // sigma1_sq < sigma_nsq and the second implies sigma12 < 0, and each of those overrides num/den below.
+      if (s2.x < eps) { g.x = 0.0f; sv.x = 0.0f; }
+      if (s2.y < eps) { g.y = 0.0f; sv.y = 0.0f; }
+      sv = f2{fmaxf(sv.x, eps), fmaxf(sv.y, eps)};
+      g = f2{fminf(g.x, a.gain_limit), fminf(g.y, a.gain_limit)};
+      const f2 svn = sv + f2{sigma_nsq, sigma_nsq};
+      const f2 narg = __builtin_elementwise_fma(g * g * s1, f2{fast_rcp(svn.x), fast_rcp(svn.y)}, f2{1.0f, 1.0f});
+      const f2 darg = __builtin_elementwise_fma(s1, f2{1.0f / sigma_nsq, 1.0f / sigma_nsq}, f2{1.0f, 1.0f});
+      f2 nv = f2{fast_log2(narg.x), fast_log2(narg.y)};
+      f2 dv = f2{fast_log2(darg.x), fast_log2(darg.y)};
+      const f2 low = __builtin_elementwise_fma(s2, f2{-sigma_max_inv, -sigma_max_inv}, f2{1.0f, 1.0f});
+      if (s12.x < 0.0f) nv.x = 0.0f;
+      if (s12.y < 0.0f) nv.y = 0.0f;
+      if (s1.x < sigma_nsq) { nv.x = low.x; dv.x = 1.0f; }
+      if (s1.y < sigma_nsq) { nv.y = low.y; dv.y = 1.0f; }
+      const f2 m = mrow2 * f2{mcol, mcol};
+      num2 = __builtin_elementwise_fma(m, nv, num2);
+      den2 = __builtin_elementwise_fma(m, dv, den2);
       __builtin_amdgcn_sched_barrier(0);  // two pixels' worth of temporaries live at a time
     }
+    num = num2.x + num2.y;
+    den = den2.x + den2.y;
   }
   const float part[2] = {num, den};
   double v[2];
@@ -377,7 +392,7 @@ hipError_t launch_dec_n(hipStream_t stream, Elem elem, const VifDecArgs& a, int 
 }
 
 constexpr int kVifN[4] = {17, 9, 5, 3};
-constexpr int kVifTW[4] = {112, 120, 124, 124};
+constexpr int kVifTW[4] = {240, 248, 252, 252};
 
 }  // namespace
 
@@ -404,10 +419,10 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
   a.taps = tap_pairs(cur, kVifN[scale], scale < 3 ? &nxt : nullptr, scale < 3 ? kVifN[scale + 1] : 0);
   if (scale < 3 && (!a.dst_ref || !a.dst_dis)) return hipErrorInvalidValue;
   switch (scale) {
-    case 0: return launch_stat_n<17, 112, 9>(stream, elem, a, n_frames);
-    case 1: return launch_stat_n<9, 120, 5>(stream, elem, a, n_frames);
-    case 2: return launch_stat_n<5, 124, 3>(stream, elem, a, n_frames);
-    case 3: return launch_stat_n<3, 124, 0>(stream, elem, a, n_frames);
+    case 0: return launch_stat_n<17, 240, 9>(stream, elem, a, n_frames);
+    case 1: return launch_stat_n<9, 248, 5>(stream, elem, a, n_frames);
+    case 2: return launch_stat_n<5, 252, 3>(stream, elem, a, n_frames);
+    case 3: return launch_stat_n<3, 252, 0>(stream, elem, a, n_frames);
   }
   return hipErrorInvalidValue;
 }
