@@ -127,68 +127,70 @@ __global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
       lcx = (t & 1) ? GW - 1 : 0;
       lcy = have ? (t >> 1) : 0;
     }
-    xs[k][0] = xs[k][1] = xs[k][2] = 0.0f;
-    if (have) {
-      const int cx = cx0 - 1 + lcx, cy = cy0 - 1 + lcy;
-      const bool valid = cx >= 0 && cx < a.ow && cy >= 0 && cy < a.oh;
-      float g = 0.0f;
-      if (valid) {
-        const f4* pl = reinterpret_cast<const f4*>(&Vlo[lcy][2 * lcx]);
-        const f4* ph = reinterpret_cast<const f4*>(&Vhi[lcy][2 * lcx]);
-        const f4 l01 = pl[0], l23 = pl[1], h01 = ph[0], h23 = ph[1];
-        const f2 l0 = f2{l01.x, l01.y}, l1 = f2{l01.z, l01.w}, l2 = f2{l23.x, l23.y}, l3 = f2{l23.z, l23.w};
-        const f2 h0 = f2{h01.x, h01.y}, h1 = f2{h01.z, h01.w}, h2 = f2{h23.x, h23.y}, h3 = f2{h23.z, h23.w};
+    // Straight-line code from here: every lane computes its coefficient (positions outside the band or
+    // the accumulation window hold finite mirrored data) and validity enters as selects / 0-1 weights.
+    // hipcc turns the reference's nested ifs into exec-mask branches otherwise (7 per coefficient).
+    if (!have) { lcx = 0; lcy = 0; }
+    const int cx = cx0 - 1 + lcx, cy = cy0 - 1 + lcy;
+    const bool valid = have && cx >= 0 && cx < a.ow && cy >= 0 && cy < a.oh;
+    const f4* pl = reinterpret_cast<const f4*>(&Vlo[lcy][2 * lcx]);
+    const f4* ph = reinterpret_cast<const f4*>(&Vhi[lcy][2 * lcx]);
+    const f4 l01 = pl[0], l23 = pl[1], h01 = ph[0], h23 = ph[1];
+    const f2 l0 = f2{l01.x, l01.y}, l1 = f2{l01.z, l01.w}, l2 = f2{l23.x, l23.y}, l3 = f2{l23.z, l23.w};
+    const f2 h0 = f2{h01.x, h01.y}, h1 = f2{h01.z, h01.w}, h2 = f2{h23.x, h23.y}, h3 = f2{h23.z, h23.w};
 #define PQA_DWT(c0, c1, c2, c3, s0, s1, s2, s3)                                                        \
   __builtin_elementwise_fma(splat(c3), s3,                                                             \
                             __builtin_elementwise_fma(splat(c2), s2, __builtin_elementwise_fma(splat(c1), s1, splat(c0) * s0)))
-        const f2 ba = PQA_DWT(lo0, lo1, lo2, lo3, l0, l1, l2, l3);  // {ref, dis} approximation
-        const f2 bv = PQA_DWT(hi0, hi1, hi2, hi3, l0, l1, l2, l3);  // vertical   (lo-v, hi-h)
-        const f2 bh = PQA_DWT(lo0, lo1, lo2, lo3, h0, h1, h2, h3);  // horizontal (hi-v, lo-h)
-        const f2 bd = PQA_DWT(hi0, hi1, hi2, hi3, h0, h1, h2, h3);  // diagonal
+    const f2 ba = PQA_DWT(lo0, lo1, lo2, lo3, l0, l1, l2, l3);  // {ref, dis} approximation
+    const f2 bv = PQA_DWT(hi0, hi1, hi2, hi3, l0, l1, l2, l3);  // vertical   (lo-v, hi-h)
+    const f2 bh = PQA_DWT(lo0, lo1, lo2, lo3, h0, h1, h2, h3);  // horizontal (hi-v, lo-h)
+    const f2 bd = PQA_DWT(hi0, hi1, hi2, hi3, h0, h1, h2, h3);  // diagonal
 #undef PQA_DWT
-        const bool inner = lcx >= 1 && lcx <= TW && lcy >= 1 && lcy <= TH;
-        if (inner && a.ll_ref) {
-          a.ll_ref[(int64_t)fr * a.ll_frame_pitch_r + (int64_t)cy * a.ll_row_pitch_r + cx] = ba.x;
-          a.ll_dis[(int64_t)fr * a.ll_frame_pitch_d + (int64_t)cy * a.ll_row_pitch_d + cx] = ba.y;
-        }
-        const float oh = bh.x, ov = bv.x, od = bd.x, th = bh.y, tv = bv.y, td = bd.y;
-        // decouple: k = clamp(t / (o + eps), 0, 1) via v_rcp_f32 + one Newton step; fmax/fmin drop a NaN
-        // (0 * inf when o + eps underflows), which the reference's comparisons would also map to 0
-        const float xh = oh + eps, xv = ov + eps, xd = od + eps;
-        const float rch = fast_rcp(xh), rcv = fast_rcp(xv), rcd = fast_rcp(xd);
-        float kh = th * rch, kv = tv * rcv, kd = td * rcd;
-        kh = fmaf(fmaf(-kh, xh, th), rch, kh);
-        kv = fmaf(fmaf(-kv, xv, tv), rcv, kv);
-        kd = fmaf(fmaf(-kd, xd, td), rcd, kd);
-        kh = fminf(fmaxf(kh, 0.0f), 1.0f);
-        kv = fminf(fmaxf(kv, 0.0f), 1.0f);
-        kd = fminf(fmaxf(kd, 0.0f), 1.0f);
-        float rh = kh * oh, rv = kv * ov, rd = kd * od;
-        const float ot_dp = oh * th + ov * tv;
-        const float o_mag_sq = oh * oh + ov * ov, t_mag_sq = th * th + tv * tv;
-        const bool angle_flag = (ot_dp >= 0.0f) && (ot_dp * ot_dp >= cos_1deg_sq * o_mag_sq * t_mag_sq);
-        if (angle_flag) {
-          const float gh = rh * a.gain_limit, gv = rv * a.gain_limit, gd = rd * a.gain_limit;
-          rh = rh > 0.0f ? fminf(gh, th) : (rh < 0.0f ? fmaxf(gh, th) : rh);
-          rv = rv > 0.0f ? fminf(gv, tv) : (rv < 0.0f ? fmaxf(gv, tv) : rv);
-          rd = rd > 0.0f ? fminf(gd, td) : (rd < 0.0f ? fmaxf(gd, td) : rd);
-        }
-        // CSF of the additive image; adm_cm_s sums the 3x3 boxes per orientation and then over
-        // orientations -- summing over orientations first is the same value up to float rounding
-        g = (1.0f / 30.0f) * (fabsf(a.rf_hv * (th - rh)) + fabsf(a.rf_hv * (tv - rv)) + fabsf(a.rf_d * (td - rd)));
-        if (inner && cx >= a.left && cx < a.right && cy >= a.top && cy < a.bottom) {
-          acc_mask |= 1u << k;
-          xs[k][0] = fabsf(rh * a.rf_hv);
-          xs[k][1] = fabsf(rv * a.rf_hv);
-          xs[k][2] = fabsf(rd * a.rf_d);
-          const float vh = fabsf(oh) * a.rf_hv, vv = fabsf(ov) * a.rf_hv, vd = fabsf(od) * a.rf_d;
-          den_h += vh * vh * vh;
-          den_v += vv * vv * vv;
-          den_d += vd * vd * vd;
-        }
-      }
-      G[lcy][lcx] = g;
+    const bool inner = valid && lcx >= 1 && lcx <= TW && lcy >= 1 && lcy <= TH;
+    if (inner && a.ll_ref) {
+      const unsigned off_r = (unsigned)cy * (unsigned)a.ll_row_pitch_r + (unsigned)cx;
+      const unsigned off_d = (unsigned)cy * (unsigned)a.ll_row_pitch_d + (unsigned)cx;
+      (a.ll_ref + (int64_t)fr * a.ll_frame_pitch_r)[off_r] = ba.x;
+      (a.ll_dis + (int64_t)fr * a.ll_frame_pitch_d)[off_d] = ba.y;
     }
+    const float oh = bh.x, ov = bv.x, od = bd.x, th = bh.y, tv = bv.y, td = bd.y;
+    // decouple: k = clamp(t / (o + eps), 0, 1) via v_rcp_f32 + one Newton step.  o + eps is either 1e-30
+    // (o == 0) or |o| >~ 1e-9 (an f32 DWT of bounded samples cannot produce a smaller non-zero value), so the
+    // reciprocal stays finite and no NaN can form.
+    const float xh = oh + eps, xv = ov + eps, xd = od + eps;
+    const float rch = fast_rcp(xh), rcv = fast_rcp(xv), rcd = fast_rcp(xd);
+    float kh = th * rch, kv = tv * rcv, kd = td * rcd;
+    kh = __builtin_amdgcn_fmed3f(fmaf(fmaf(-kh, xh, th), rch, kh), 0.0f, 1.0f);
+    kv = __builtin_amdgcn_fmed3f(fmaf(fmaf(-kv, xv, tv), rcv, kv), 0.0f, 1.0f);
+    kd = __builtin_amdgcn_fmed3f(fmaf(fmaf(-kd, xd, td), rcd, kd), 0.0f, 1.0f);
+    float rh = kh * oh, rv = kv * ov, rd = kd * od;
+    const float ot_dp = oh * th + ov * tv;
+    const float o_mag_sq = oh * oh + ov * ov, t_mag_sq = th * th + tv * tv;
+    const bool angle_flag = (ot_dp >= 0.0f) && (ot_dp * ot_dp >= cos_1deg_sq * o_mag_sq * t_mag_sq);
+    {
+      // enhancement-gain limit: r > 0 -> min(r*limit, t);  r < 0 -> max(r*limit, t);  r == 0 stays
+      const float gh = rh * a.gain_limit, gv = rv * a.gain_limit, gd = rd * a.gain_limit;
+      const float ch = rh > 0.0f ? (gh < th ? gh : th) : (gh > th ? gh : th);
+      const float cv = rv > 0.0f ? (gv < tv ? gv : tv) : (gv > tv ? gv : tv);
+      const float cd = rd > 0.0f ? (gd < td ? gd : td) : (gd > td ? gd : td);
+      rh = (angle_flag && rh != 0.0f) ? ch : rh;
+      rv = (angle_flag && rv != 0.0f) ? cv : rv;
+      rd = (angle_flag && rd != 0.0f) ? cd : rd;
+    }
+    // CSF of the additive image; adm_cm_s sums the 3x3 boxes per orientation and then over
+    // orientations -- summing over orientations first is the same value up to float rounding
+    const float g = (1.0f / 30.0f) * (fabsf(a.rf_hv * (th - rh)) + fabsf(a.rf_hv * (tv - rv)) + fabsf(a.rf_d * (td - rd)));
+    const bool in_win = inner && cx >= a.left && cx < a.right && cy >= a.top && cy < a.bottom;
+    const float mw = in_win ? 1.0f : 0.0f;
+    acc_mask |= in_win ? (1u << k) : 0u;
+    xs[k][0] = fabsf(rh * a.rf_hv);
+    xs[k][1] = fabsf(rv * a.rf_hv);
+    xs[k][2] = fabsf(rd * a.rf_d);
+    const float vh = fabsf(oh) * a.rf_hv, vv = fabsf(ov) * a.rf_hv, vd = fabsf(od) * a.rf_d;
+    den_h = fmaf(mw * vh, vh * vh, den_h);
+    den_v = fmaf(mw * vv, vv * vv, den_v);
+    den_d = fmaf(mw * vd, vd * vd, den_d);
+    if (have) G[lcy][lcx] = valid ? g : 0.0f;
   }
   __syncthreads();
 
