@@ -167,16 +167,13 @@ __global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
     const float ot_dp = oh * th + ov * tv;
     const float o_mag_sq = oh * oh + ov * ov, t_mag_sq = th * th + tv * tv;
     const bool angle_flag = (ot_dp >= 0.0f) && (ot_dp * ot_dp >= cos_1deg_sq * o_mag_sq * t_mag_sq);
-    {
-      // enhancement-gain limit: r > 0 -> min(r*limit, t);  r < 0 -> max(r*limit, t);  r == 0 stays
-      const float gh = rh * a.gain_limit, gv = rv * a.gain_limit, gd = rd * a.gain_limit;
-      const float ch = rh > 0.0f ? (gh < th ? gh : th) : (gh > th ? gh : th);
-      const float cv = rv > 0.0f ? (gv < tv ? gv : tv) : (gv > tv ? gv : tv);
-      const float cd = rd > 0.0f ? (gd < td ? gd : td) : (gd > td ? gd : td);
-      rh = (angle_flag && rh != 0.0f) ? ch : rh;
-      rv = (angle_flag && rv != 0.0f) ? cv : rv;
-      rd = (angle_flag && rd != 0.0f) ? cd : rd;
-    }
+    // enhancement-gain limit under the angle test: r > 0 -> min(r*limit, t); r < 0 -> max(r*limit, t);
+    // r == 0 stays.  Because r = clamp(t/o, 0, 1) * o lies between 0 and t and limit >= 1, all three cases
+    // are the median of {r, r*limit, t}: one v_med3_f32 (differs from the branchy form only when k*o
+    // rounds 1 ulp past t).
+    rh = angle_flag ? __builtin_amdgcn_fmed3f(rh, rh * a.gain_limit, th) : rh;
+    rv = angle_flag ? __builtin_amdgcn_fmed3f(rv, rv * a.gain_limit, tv) : rv;
+    rd = angle_flag ? __builtin_amdgcn_fmed3f(rd, rd * a.gain_limit, td) : rd;
     // CSF of the additive image; adm_cm_s sums the 3x3 boxes per orientation and then over
     // orientations -- summing over orientations first is the same value up to float rounding
     const float g = (1.0f / 30.0f) * (fabsf(a.rf_hv * (th - rh)) + fabsf(a.rf_hv * (tv - rv)) + fabsf(a.rf_d * (td - rd)));
