@@ -169,7 +169,7 @@ def main():
             frames_per_launch = k["frames"] / k["launches"]
             achieved = b_alg * frames_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = _traffic_from_profiles(args.workload)
-            out["roofline"] = {"bound": "hbm", "kernel": "vif_stat_kernel<u8,17,112> (VIF scale 0)",
+            out["roofline"] = {"bound": "hbm", "kernel": "vif_stat_kernel<u8,17,240,9> (VIF scale 0 + fused decimation to scale 1)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5),
                                "traffic": traffic,
