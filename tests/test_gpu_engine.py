@@ -117,3 +117,42 @@ def test_one_oracle_frame_at_1080p(oracle32):
     rel = np.abs(got[:, :16] - exp[:, :16]) / np.abs(exp[:, :16])
     # motion: the f32 oracle sums 2M pixels in float like libvmaf (~1e-6 relative); the kernel sums in double
     assert rel.max() < 5e-5 and abs(got[1, 16] - exp[1, 16]) < 5e-6 * exp[1, 16] + 2e-5
+
+
+def test_score_cli_single_and_torchrun(tmp_path):
+    """python -m pqa2_amd.score, plain and under torch.distributed.run (1 rank on this 1-GPU box)."""
+    import subprocess
+    import sys
+    rp, dp, refs, diss = _pair(tmp_path, 256, 144, 6)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    j1, j2 = str(tmp_path / "a.json"), str(tmp_path / "b.json")
+    r = subprocess.run([sys.executable, "-m", "pqa2_amd.score", rp, dp, "--json", j1, "--psnr-log", str(tmp_path / "p.txt")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "frame=" in r.stderr and "VMAF score:" in r.stderr
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", "-m", "pqa2_amd.score", rp, dp, "--json", j2],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a, b = json.load(open(j1)), json.load(open(j2))
+    assert [f["metrics"]["vmaf"] for f in a["frames"]] == [f["metrics"]["vmaf"] for f in b["frames"]]
+    assert len(open(tmp_path / "p.txt").read().strip().split("\n")) == 6
+    # unreadable input -> non-zero exit and a one-line error, like an ffmpeg child
+    r = subprocess.run([sys.executable, "-m", "pqa2_amd.score", rp, str(tmp_path / "missing.y4m"), "--json", j1],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "error" in r.stderr
+
+
+def test_ragged_clip_lengths_use_the_shorter(tmp_path):
+    from pqa2_amd.pipeline import score_files
+    refs, diss = synth.make_clip(128, 96, 5, 8, chroma=True)
+    info = synth.clip_info(128, 96)
+    rp, dp = str(tmp_path / "r.y4m"), str(tmp_path / "d.y4m")
+    yuvio.write_y4m(rp, refs, info)
+    yuvio.write_y4m(dp, diss[:3], info)
+    res = score_files(rp, dp, "vmaf_v0.6.1")
+    assert res["records"].shape[0] == 3 and list(res["frame_indices"]) == [0, 1, 2]
+    yuvio.write_y4m(dp, [], info)
+    with pytest.raises(ValueError):
+        score_files(rp, dp, "vmaf_v0.6.1")

@@ -183,3 +183,77 @@ def test_bad_config_is_rejected():
         _engine(8, 8)
     with pytest.raises(N.PqaError):
         _engine(64, 64, bit_depth=9)
+
+
+@pytest.mark.parametrize("shift,tag", [((0, 0), "444"), ((1, 0), "422"), ((1, 1), "420")])
+def test_chroma_layouts_psnr_ssim(oracle32, shift, tag):
+    """4:4:4 / 4:2:2 / 4:2:0 chroma planes through the PSNR / SSIM kernels (odd luma size: ceil-shifted chroma)."""
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import sse_from_records
+    w, h = 150, 86
+    cw, ch = -(-w >> shift[0]), -(-h >> shift[1])
+    rng = np.random.default_rng(5)
+    ref = [rng.integers(0, 256, (h, w), dtype=np.uint8)] + [rng.integers(0, 256, (ch, cw), dtype=np.uint8) for _ in range(2)]
+    dis = [np.clip(p.astype(np.int16) + rng.integers(-9, 10, p.shape), 0, 255).astype(np.uint8) for p in ref]
+    with _engine(w, h, n_planes=3, chroma_shift=shift, features=N.FEAT_PSNR | N.FEAT_SSIM) as eng:
+        eng.submit(0, ref, dis)
+        rec = eng.collect(0, 1)
+    sse = sse_from_records(rec)
+    for p in range(3):
+        assert int(sse[0, p]) == oracle32.sse_plane(dis[p], ref[p], 8), (tag, p)
+        assert abs(rec[0, 17 + p] - oracle32.ssim_plane(dis[p], ref[p], 8)) < 1e-9, (tag, p)
+
+
+def test_unaligned_pitch_and_strided_rows(oracle64):
+    """Host planes that are views with a row stride (cropped from a wider buffer) and an odd width."""
+    w, h = 203, 77
+    big_r, big_d = synth.make_clip(256, 96, 2, 8, chroma=False)
+    refs = [[f[0][5:5 + h, 11:11 + w]] for f in big_r]      # non-contiguous views, odd offsets
+    diss = [[f[0][5:5 + h, 11:11 + w]] for f in big_d]
+    exp = oracle64.clip_features([np.ascontiguousarray(r[0]) for r in refs], [np.ascontiguousarray(d[0]) for d in diss], 8)
+    with _engine(w, h) as eng:
+        for i in range(2):
+            eng.submit(i, refs[i], diss[i])
+        got = eng.collect(0, 2)[:, :17]
+    rel = np.abs(got[:, :16] - exp[:, :16]) / np.abs(exp[:, :16])
+    assert rel.max() < REL_TOL and np.abs(got[:, 16] - exp[:, 16]).max() < MOTION_ATOL
+
+
+def test_torch_stream_and_profile_hooks():
+    import torch
+    w, h, n = 320, 180, 4
+    refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+    R = torch.from_numpy(np.stack([r[0] for r in refs])).cuda()
+    D = torch.from_numpy(np.stack([d[0] for d in diss])).cuda()
+    torch.cuda.synchronize()
+    with _engine(w, h) as eng:
+        eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [w], [w * h])
+        base = eng.collect(0, n)
+    s = torch.cuda.Stream()
+    with _engine(w, h) as eng:
+        eng._check(eng.lib.pqa_set_stream(eng._ctx, s.cuda_stream))
+        eng.profile_enable([0, 7, 11])
+        eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [w], [w * h])
+        got = eng.collect(0, n)
+        prof = eng.profile_read()
+    assert np.array_equal(base, got)
+    assert prof["vif_stat_s0"]["launches"] == 1 and prof["vif_stat_s0"]["frames"] == n and prof["vif_stat_s0"]["ms"] > 0
+    assert prof["adm_scale_s0"]["launches"] == 1 and prof["motion"]["launches"] == 1
+    assert prof["vif_stat_s1"]["launches"] == 0        # not in the mask
+
+
+def test_result_ring_wraps():
+    w, h, n = 64, 64, 10
+    refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+    with _engine(w, h, max_batch=2) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        full = eng.collect(0, n)
+    with _engine(w, h, max_batch=2, result_capacity=4) as eng:   # ring of 4 records
+        out = []
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+            if i % 3 == 2:
+                out.append(eng.collect(i - 2, 3))
+        out.append(eng.collect(9, 1))
+    assert np.array_equal(np.concatenate(out), full)
