@@ -41,8 +41,16 @@ class SvmModel:
     def predict(self, feats: np.ndarray, enable_transform: bool = False) -> np.ndarray:
         """feats [n, n_features] in model order -> scores [n]."""
         x = np.asarray(feats, np.float64) * self.slopes[1:] + self.intercepts[1:]
-        d2 = ((x[:, None, :] - self.sv[None, :, :]) ** 2).sum(-1)
-        y = (np.exp(-self.gamma * d2) * self.coef[None, :]).sum(-1) - self.rho
+        # ||x - sv||^2 = ||x||^2 + ||sv||^2 - 2 x.sv : one small GEMM instead of an [n, n_sv, 6] temporary
+        # (f64; features and SVs are O(1), so the cancellation costs ~1e-15 -- far below libvmaf's %.6f)
+        d2 = x @ self.sv.T
+        d2 *= -2.0
+        d2 += (x * x).sum(1)[:, None]
+        d2 += (self.sv * self.sv).sum(1)[None, :]
+        np.maximum(d2, 0.0, out=d2)
+        d2 *= -self.gamma
+        np.exp(d2, out=d2)
+        y = d2 @ self.coef - self.rho
         y = (y - self.intercepts[0]) / self.slopes[0]
         if enable_transform and self.score_transform:
             t = self.score_transform
