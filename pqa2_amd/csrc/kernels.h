@@ -56,7 +56,7 @@ hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun r
                             MutPlaneRun ll_dis, double* partials);
 
 // ---- motion ---------------------------------------------------------------------------------
-constexpr int kMotionTileW = 124, kMotionTileH = 16;
+constexpr int kMotionTileW = 252, kMotionTileH = 16;
 inline int motion_tiles(int w, int h) {
   return ((w + kMotionTileW - 1) / kMotionTileW) * ((h + kMotionTileH - 1) / kMotionTileH);
 }

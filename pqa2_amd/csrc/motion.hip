@@ -25,9 +25,9 @@ struct MotionArgs {
   f2 ht[5];  // horizontal splats {c[k], c[k]}
 };
 
-constexpr int TW = kMotionTileW, TH = kMotionTileH, R = 2, COLS = TW + 4, NSEG = TW / 4, S = 8, NIN = S + 4;
-constexpr int kP2 = 130;  // float2 pitch == 2 (mod 32): conflict-free ds_read_b128 (same map as vif.hip)
-static_assert(COLS <= 128 && NSEG <= 32 && TW % 4 == 0, "tile map");
+constexpr int TW = kMotionTileW, TH = kMotionTileH, R = 2, COLS = TW + 4, NSEG = TW / 4, S = 16, NIN = S + 4;
+constexpr int kP2 = 258;  // float2 pitch == 2 (mod 32): conflict-free ds_read_b128
+static_assert(COLS <= 256 && NSEG <= 64 && TW % 4 == 0 && TH == S, "one column per thread, one 16-row strip");
 
 // Same packed layout as the VIF kernel: float2 = {row 2p, row 2p+1} of one column; the vertical pass
 // uses tap pairs with the input broadcast, the horizontal pass broadcast taps with input pairs.
@@ -60,8 +60,7 @@ __global__ __launch_bounds__(kBlock) void motion_kernel(const MotionArgs a) {
   const rsrc_t rsrc_p = make_rsrc(prev, (unsigned)a.h * pitch_p * (unsigned)sizeof(T));
   const int x0 = tx * TW, y0 = ty * TH;
   {
-    const int col = tid & 127;
-    const int seg = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int col = tid;  // one column per thread; the 16-row strip is the whole tile: rows are wave-uniform
     if (col < COLS) {
       const unsigned gx = (unsigned)mirror1(x0 - R + col, a.w);
       f2 acc[S / 2];
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void motion_kernel(const MotionArgs a) {
       for (int p = 0; p < S / 2; ++p) acc[p] = f2{0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < NIN; ++j) {
-        const unsigned gy = (unsigned)mirror1(y0 + seg * S - R + j, a.h);
+        const unsigned gy = (unsigned)mirror1(y0 - R + j, a.h);
         const int c = (int)buf_load<T>(rsrc_c, gx, gy * pitch_c);
         const int p0 = (int)buf_load<T>(rsrc_p, gx, gy * pitch_p);
         const float d = (float)(c - p0);
@@ -80,36 +79,42 @@ __global__ __launch_bounds__(kBlock) void motion_kernel(const MotionArgs a) {
         }
       }
 #pragma unroll
-      for (int p = 0; p < S / 2; ++p) sv[seg * (S / 2) + p][col] = acc[p];
+      for (int p = 0; p < S / 2; ++p) sv[p][col] = acc[p];
     }
   }
   __syncthreads();
+  // lane l: row pair l & 7, segment wave + 4 * (l >> 3) + 32 * round: the 16-byte chunk index of a lane is
+  // (rp + 8 * (j & 1) + const) mod 16, distinct inside every ds_read_b128 lane group
   const int wave = tid >> 6, lane = tid & 63;
-  const int rp = lane & 7, seg = wave + 4 * (lane >> 3);
+  const int rp = lane & 7;
   float sad = 0.0f;
-  if (seg < NSEG) {
-    f2 in[8];
-    const f4* p = reinterpret_cast<const f4*>(&sv[rp][seg * 4]);
+  const int gyA = y0 + 2 * rp;
+  const float mA = gyA < a.h ? 1.0f : 0.0f, mB = gyA + 1 < a.h ? 1.0f : 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f4 v = p[q];
-      in[2 * q] = f2{v.x, v.y};
-      in[2 * q + 1] = f2{v.z, v.w};
-    }
-    f2 out[4];
+  for (int round = 0; round < 2; ++round) {
+    const int seg = wave + 4 * (lane >> 3) + 32 * round;
+    if (seg < NSEG) {
+      f2 in[8];
+      const f4* p = reinterpret_cast<const f4*>(&sv[rp][seg * 4]);
 #pragma unroll
-    for (int o = 0; o < 4; ++o) out[o] = f2{0.0f, 0.0f};
+      for (int q = 0; q < 4; ++q) {
+        const f4 v = p[q];
+        in[2 * q] = f2{v.x, v.y};
+        in[2 * q + 1] = f2{v.z, v.w};
+      }
+      f2 out[4];
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+      for (int o = 0; o < 4; ++o) out[o] = f2{0.0f, 0.0f};
 #pragma unroll
-      for (int o = 0; o < 4; ++o) out[o] = __builtin_elementwise_fma(a.ht[k], in[o + k], out[o]);
-    const int gyA = y0 + 2 * rp;
-    const float mA = gyA < a.h ? 1.0f : 0.0f, mB = gyA + 1 < a.h ? 1.0f : 0.0f;
+      for (int k = 0; k < 5; ++k)
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const float mc = (x0 + seg * 4 + o) < a.w ? 1.0f : 0.0f;
-      sad = fmaf(mc * mA, fabsf(out[o].x), sad);
-      sad = fmaf(mc * mB, fabsf(out[o].y), sad);
+        for (int o = 0; o < 4; ++o) out[o] = __builtin_elementwise_fma(a.ht[k], in[o + k], out[o]);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const float mc = (x0 + seg * 4 + o) < a.w ? 1.0f : 0.0f;
+        sad = fmaf(mc * mA, fabsf(out[o].x), sad);
+        sad = fmaf(mc * mB, fabsf(out[o].y), sad);
+      }
     }
   }
   const float part[1] = {sad};
