@@ -168,7 +168,8 @@ def main():
             avg_ms = k["ms"] / k["launches"]
             frames_per_launch = k["frames"] / k["launches"]
             achieved = b_alg * frames_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = _traffic_from_profiles(args.workload)
+            per_frame = _traffic_from_profiles(args.workload)
+            traffic = int(per_frame * frames_per_launch) if per_frame else None
             out["roofline"] = {"bound": "hbm", "kernel": "vif_stat_kernel<u8,17,240,9> (VIF scale 0 + fused decimation to scale 1)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -191,12 +192,13 @@ def main():
 
 
 def _traffic_from_profiles(workload: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes, if any."""
+    """HBM bytes per FRAME of the dominant kernel from the committed rocprofv3 --pmc passes, if any
+    (bench.py cannot collect PMC counters itself; tools/summarize_rocprof.py writes this file)."""
     p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(p) as f:
             d = json.load(f)
-        return d.get(workload, {}).get("vif_stat_s0_bytes_per_launch")
+        return d.get(workload, {}).get("vif_stat_s0_bytes_per_frame")
     except Exception:
         return None
 

@@ -65,7 +65,7 @@ if pmc:
     tj = os.path.join(root, "hbm_traffic.json")
     cur = json.load(open(tj)) if os.path.exists(tj) else {}
     if k0:
-        cur[a.workload] = {"vif_stat_s0_bytes_per_launch": int(pmc[k0]["hbm_bytes_per_launch_corrected"]),
-                           "frames_per_launch": a.frames_per_launch, "source": f"profiles/{a.tag}_pmc.json"}
+        cur[a.workload] = {"vif_stat_s0_bytes_per_frame": int(pmc[k0]["hbm_bytes_per_frame_corrected"]),
+                           "measured_at_frames_per_launch": a.frames_per_launch, "source": f"profiles/{a.tag}_pmc.json"}
         json.dump(cur, open(tj, "w"), indent=1)
 print("ok")
