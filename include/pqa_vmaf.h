@@ -150,7 +150,8 @@ PQA_API int pqa_reset(pqa_ctx* ctx);
 PQA_API const char* pqa_last_error(const pqa_ctx* ctx);
 
 /* Measurement hooks (bench.py): HIP-event timing of individual kernels on the context's stream.
- * kernel ids: 0..3 vif_stat scale s, 4..6 vif_decimate to scale 1..3, 7..10 adm scale s,
+ * kernel ids: 0..3 vif_stat scale s (each also produces the next scale's planes), 4..6 reserved,
+ * 7..10 adm scale s,
  * 11 motion, 12 sse, 13 ssim, 14 finalize.
  * pqa_profile_enable(ctx, 0) stops, (ctx, 1) times every kernel, (ctx, mask << 1) only the kernels whose bit
  * is set in mask (event records between kernels are not free: ~10 % of a step when every kernel is timed). */

@@ -37,11 +37,6 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
                            int w, int h, float inv_scale, float gain_limit, double* partials,
                            MutPlaneRun next_ref, MutPlaneRun next_dis);
 
-// Stand-alone decimation (same arithmetic as the fused path; kept for tests and profiling A/B).
-hipError_t launch_vif_decimate(hipStream_t stream, int dst_scale, Elem elem, PlaneRun ref, PlaneRun dis,
-                               int n_frames, int w, int h, float inv_scale, MutPlaneRun dst_ref,
-                               MutPlaneRun dst_dis);
-
 // ---- ADM ------------------------------------------------------------------------------------
 constexpr int kAdmTileW = 60, kAdmTileH = 16;  // 2*(60+2)+2 = 126 input columns: one per lane
 inline int adm_tiles_x(int band_w) { return (band_w + kAdmTileW - 1) / kAdmTileW; }

@@ -122,8 +122,8 @@ int dev_alloc(pqa_ctx* c, T** out, size_t count) {
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 static const char* kProfNames[PQA_PROF_KERNELS] = {
-    "vif_stat_s0", "vif_stat_s1", "vif_stat_s2", "vif_stat_s3", "vif_decimate_s1", "vif_decimate_s2",
-    "vif_decimate_s3", "adm_scale_s0", "adm_scale_s1", "adm_scale_s2", "adm_scale_s3", "motion", "sse",
+    "vif_stat_s0", "vif_stat_s1", "vif_stat_s2", "vif_stat_s3", "reserved4", "reserved5",
+    "reserved6", "adm_scale_s0", "adm_scale_s1", "adm_scale_s2", "adm_scale_s3", "motion", "sse",
     "ssim", "finalize"};
 
 struct ProfScope {

@@ -294,81 +294,6 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
   }
 }
 
-// ---- decimation: filter with the destination scale's kernel, keep even samples ----------------
-struct VifDecArgs {
-  const void* ref;
-  const void* dis;
-  int64_t row_pitch_r, frame_pitch_r, row_pitch_d, frame_pitch_d;
-  int w, h, ow, oh, tiles_x, n_tiles;
-  float inv_scale;
-  float* dst_ref;
-  float* dst_dis;
-  int64_t dst_row_pitch_r, dst_frame_pitch_r, dst_row_pitch_d, dst_frame_pitch_d;
-  Taps taps;
-};
-
-constexpr int kDecTW = 64, kDecTH = 16;  // output tile
-
-template <typename T, int N>
-__global__ __launch_bounds__(kBlock) void vif_dec_kernel(const VifDecArgs a) {
-  constexpr int R = N / 2, COLS = 2 * kDecTW - 2 + N, S = 8, NIN = 2 * S - 2 + N, PD = COLS + 1;
-  __shared__ float sv[2][kDecTH][PD];
-  const int tile = xcd_remap(blockIdx.x, a.n_tiles);
-  const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-  const int fr = blockIdx.y;
-  const T* __restrict__ ref = (const T*)a.ref + (int64_t)fr * a.frame_pitch_r;
-  const T* __restrict__ dis = (const T*)a.dis + (int64_t)fr * a.frame_pitch_d;
-  const int ox0 = tx * kDecTW, oy0 = ty * kDecTH;
-  const int tid = threadIdx.x;
-
-  // vertical pass at even rows only: lane <-> input column
-  for (int item = tid; item < COLS * (kDecTH / S); item += kBlock) {
-    const int col = item % COLS, seg = item / COLS;
-    const int gx = mirror(2 * ox0 - R + col, a.w);
-    float acc[S][2];
-#pragma unroll
-    for (int o = 0; o < S; ++o) acc[o][0] = acc[o][1] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NIN; ++j) {
-      const int gy = mirror(2 * (oy0 + seg * S) - R + j, a.h);
-      const float r = PixIO<T>::load(ref + (int64_t)gy * a.row_pitch_r + gx, a.inv_scale);
-      const float d = PixIO<T>::load(dis + (int64_t)gy * a.row_pitch_d + gx, a.inv_scale);
-#pragma unroll
-      for (int o = 0; o < S; ++o) {
-        const int k = j - 2 * o;
-        if (k >= 0 && k < N) {
-          acc[o][0] = fmaf(a.taps.f[k], r, acc[o][0]);
-          acc[o][1] = fmaf(a.taps.f[k], d, acc[o][1]);
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 0; o < S; ++o) {
-      sv[0][seg * S + o][col] = acc[o][0];
-      sv[1][seg * S + o][col] = acc[o][1];
-    }
-  }
-  __syncthreads();
-
-  // horizontal pass at even columns: lane <-> output column, 4 rows per thread
-  const int oc = tid & 63, rg = tid >> 6;
-  const int gx = ox0 + oc;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = rg * 4 + q, gy = oy0 + row;
-    float ar = 0.0f, ad = 0.0f;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      ar = fmaf(a.taps.f[k], sv[0][row][2 * oc + k], ar);
-      ad = fmaf(a.taps.f[k], sv[1][row][2 * oc + k], ad);
-    }
-    if (gx < a.ow && gy < a.oh) {
-      a.dst_ref[(int64_t)fr * a.dst_frame_pitch_r + (int64_t)gy * a.dst_row_pitch_r + gx] = ar;
-      a.dst_dis[(int64_t)fr * a.dst_frame_pitch_d + (int64_t)gy * a.dst_row_pitch_d + gx] = ad;
-    }
-  }
-}
-
 template <int N, int TW, int ND>
 hipError_t launch_stat_n(hipStream_t stream, Elem elem, const VifStatArgs& a, int n_frames) {
   const dim3 grid(a.n_tiles, n_frames), block(kBlock);
@@ -376,17 +301,6 @@ hipError_t launch_stat_n(hipStream_t stream, Elem elem, const VifStatArgs& a, in
     case ELEM_U8: hipLaunchKernelGGL((vif_stat_kernel<uint8_t, N, TW, ND>), grid, block, 0, stream, a); break;
     case ELEM_U16: hipLaunchKernelGGL((vif_stat_kernel<uint16_t, N, TW, ND>), grid, block, 0, stream, a); break;
     case ELEM_F32: hipLaunchKernelGGL((vif_stat_kernel<float, N, TW, ND>), grid, block, 0, stream, a); break;
-  }
-  return hipGetLastError();
-}
-
-template <int N>
-hipError_t launch_dec_n(hipStream_t stream, Elem elem, const VifDecArgs& a, int n_frames) {
-  const dim3 grid(a.n_tiles, n_frames), block(kBlock);
-  switch (elem) {
-    case ELEM_U8: hipLaunchKernelGGL((vif_dec_kernel<uint8_t, N>), grid, block, 0, stream, a); break;
-    case ELEM_U16: hipLaunchKernelGGL((vif_dec_kernel<uint16_t, N>), grid, block, 0, stream, a); break;
-    case ELEM_F32: hipLaunchKernelGGL((vif_dec_kernel<float, N>), grid, block, 0, stream, a); break;
   }
   return hipGetLastError();
 }
@@ -423,31 +337,6 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
     case 1: return launch_stat_n<9, 248, 5>(stream, elem, a, n_frames);
     case 2: return launch_stat_n<5, 252, 3>(stream, elem, a, n_frames);
     case 3: return launch_stat_n<3, 252, 0>(stream, elem, a, n_frames);
-  }
-  return hipErrorInvalidValue;
-}
-
-hipError_t launch_vif_decimate(hipStream_t stream, int dst_scale, Elem elem, PlaneRun ref, PlaneRun dis,
-                               int n_frames, int w, int h, float inv_scale, MutPlaneRun dst_ref,
-                               MutPlaneRun dst_dis) {
-  if (n_frames <= 0) return hipSuccess;
-  VifDecArgs a{};
-  a.ref = ref.base; a.dis = dis.base;
-  a.row_pitch_r = ref.row_pitch; a.frame_pitch_r = ref.frame_pitch;
-  a.row_pitch_d = dis.row_pitch; a.frame_pitch_d = dis.frame_pitch;
-  a.w = w; a.h = h; a.ow = w / 2; a.oh = h / 2;
-  if (a.ow <= 0 || a.oh <= 0) return hipSuccess;
-  a.tiles_x = (a.ow + kDecTW - 1) / kDecTW;
-  a.n_tiles = a.tiles_x * ((a.oh + kDecTH - 1) / kDecTH);
-  a.inv_scale = inv_scale;
-  a.dst_ref = (float*)dst_ref.base; a.dst_dis = (float*)dst_dis.base;
-  a.dst_row_pitch_r = dst_ref.row_pitch; a.dst_frame_pitch_r = dst_ref.frame_pitch;
-  a.dst_row_pitch_d = dst_dis.row_pitch; a.dst_frame_pitch_d = dst_dis.frame_pitch;
-  a.taps = gaussian_taps(kVifN[dst_scale]);
-  switch (dst_scale) {
-    case 1: return launch_dec_n<9>(stream, elem, a, n_frames);
-    case 2: return launch_dec_n<5>(stream, elem, a, n_frames);
-    case 3: return launch_dec_n<3>(stream, elem, a, n_frames);
   }
   return hipErrorInvalidValue;
 }
