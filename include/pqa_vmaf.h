@@ -149,6 +149,15 @@ PQA_API int pqa_reset(pqa_ctx* ctx);
 /* Text of the most recent failure on this context (ctx == NULL: last pqa_create failure). */
 PQA_API const char* pqa_last_error(const pqa_ctx* ctx);
 
+/* Per-frame luma statistics of a device-resident clip: out[n_frames][3] (host) = {sum, sum of squares,
+ * count(sample > threshold)}, exact integers.  mean / std / white-pixel ratio follow in float64 on the host.
+ * Replaces the cv2 loops np.mean(gray) / np.std(gray) / np.sum(gray > threshold) of the reference's white
+ * bookend-frame detection (app/bookend_alignment.py:796-800, 902-904, 998-1020; app/reference_analyzer.py:
+ * 127-144) -- the step that runs right before analyze_videos.  n_frames <= max_batch per call is NOT required
+ * (the call loops).  Synchronous. */
+PQA_API int pqa_luma_stats_device(pqa_ctx* ctx, const void* luma, int64_t row_pitch, int64_t frame_pitch,
+                                  int32_t n_frames, uint32_t threshold, uint64_t* out);
+
 /* Measurement hooks (bench.py): HIP-event timing of individual kernels on the context's stream.
  * kernel ids: 0..3 vif_stat scale s (each also produces the next scale's planes), 4..6 reserved,
  * 7..10 adm scale s,

@@ -76,6 +76,12 @@ inline int ssim_tiles(int w, int h) {
 hipError_t launch_ssim(hipStream_t stream, Elem elem, PlaneRun main, PlaneRun ref, int n_frames, int w, int h,
                        int max_value, double* partials);
 
+// ---- luma statistics (white bookend-frame detection, the step before the scoring path) ----------
+constexpr int kLumaBlocks = 128;
+// out: [n_frames][3] uint64 = {sum, sum of squares, count(sample > threshold)}; partials: [n_frames][kLumaBlocks][3].
+hipError_t launch_luma_stats(hipStream_t stream, Elem elem, PlaneRun luma, int n_frames, int w, int h,
+                             unsigned threshold, unsigned long long* partials, unsigned long long* out);
+
 // ---- finalize -------------------------------------------------------------------------------
 // Fixed-order reduction of every partial array of a batch into per-frame records.
 struct FinalizeArgs {

@@ -1,0 +1,113 @@
+// Per-frame luma statistics for white "bookend" frame detection -- the step right before the scoring
+// path in the reference: BookendAligner samples frames and takes np.mean(gray), np.std(gray) and the
+// fraction of pixels above a threshold (app/bookend_alignment.py:796-800, 902-904, 998-1020;
+// app/reference_analyzer.py:127-144).  Here the three reductions are exact integers per frame
+// (sum, sum of squares, count above threshold); mean / std / ratio follow on the host in float64.
+// Pure streaming: one 16-byte load per lane per step, v_dot4_u32_u8 for both sums -> HBM-bound.
+#include "kernels.h"
+#include "pqa_device.h"
+
+namespace pqa {
+namespace {
+
+struct LumaArgs {
+  const void* base;
+  int64_t row_pitch, frame_pitch;
+  int w, h;
+  unsigned threshold;
+  unsigned long long* partials;  // [n_frames][kLumaBlocks][3]
+};
+
+__device__ __forceinline__ unsigned count_gt4(unsigned x, unsigned thr) {
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c += ((x >> (8 * i)) & 0xffu) > thr ? 1u : 0u;
+  return c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void luma_stats_kernel(const LumaArgs a) {
+  __shared__ unsigned long long red[12];
+  const int fr = blockIdx.y;
+  const T* __restrict__ p = (const T*)a.base + (int64_t)fr * a.frame_pitch;
+  const int tid = threadIdx.x;
+  constexpr int VEC = 16 / sizeof(T);
+  const bool aligned = ((a.row_pitch * sizeof(T)) % 16 == 0) && ((uintptr_t)p % 16 == 0);
+  const int wv = aligned ? a.w / VEC : 0;
+  unsigned long long sum = 0, sq = 0, cnt = 0;
+  for (int y = blockIdx.x; y < a.h; y += gridDim.x) {
+    const T* row = p + (int64_t)y * a.row_pitch;
+    unsigned rs = 0, rq = 0, rc = 0;  // per-row 32-bit accumulators (8-bit rows cannot overflow them)
+    for (int v = tid; v < wv; v += kBlock) {
+      const uint4 x = reinterpret_cast<const uint4*>(row)[v];
+      const unsigned xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (sizeof(T) == 1) {
+          rs = __builtin_amdgcn_udot4(xs[i], 0x01010101u, rs, false);
+          rq = __builtin_amdgcn_udot4(xs[i], xs[i], rq, false);
+          rc += count_gt4(xs[i], a.threshold);
+        } else {
+          const unsigned lo = xs[i] & 0xffffu, hi = xs[i] >> 16;
+          sum += lo + hi;
+          sq += (unsigned long long)lo * lo + (unsigned long long)hi * hi;
+          rc += (lo > a.threshold ? 1u : 0u) + (hi > a.threshold ? 1u : 0u);
+        }
+      }
+    }
+    for (int x = wv * VEC + tid; x < a.w; x += kBlock) {
+      const unsigned v = row[x];
+      sum += v;
+      sq += (unsigned long long)v * v;
+      rc += v > a.threshold ? 1u : 0u;
+    }
+    sum += rs; sq += rq; cnt += rc;
+  }
+  unsigned long long v[3] = {sum, sq, cnt};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+    if ((tid & 63) == 0) red[(tid >> 6) * 3 + i] = v[i];
+  }
+  __syncthreads();
+  if (tid < 3) a.partials[((int64_t)fr * gridDim.x + blockIdx.x) * 3 + tid] = (red[tid] + red[3 + tid]) + (red[6 + tid] + red[9 + tid]);
+}
+
+__global__ __launch_bounds__(kBlock) void luma_stats_finalize(const unsigned long long* partials, int n_blocks,
+                                                               unsigned long long* out) {
+  __shared__ unsigned long long red[12];
+  const int fr = blockIdx.x, tid = threadIdx.x;
+  unsigned long long v[3] = {0, 0, 0};
+  for (int b = tid; b < n_blocks; b += kBlock)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] += partials[((int64_t)fr * n_blocks + b) * 3 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+    if ((tid & 63) == 0) red[(tid >> 6) * 3 + i] = v[i];
+  }
+  __syncthreads();
+  if (tid < 3) out[(int64_t)fr * 3 + tid] = (red[tid] + red[3 + tid]) + (red[6 + tid] + red[9 + tid]);
+}
+
+}  // namespace
+
+hipError_t launch_luma_stats(hipStream_t stream, Elem elem, PlaneRun luma, int n_frames, int w, int h,
+                             unsigned threshold, unsigned long long* partials, unsigned long long* out) {
+  if (n_frames <= 0) return hipSuccess;
+  LumaArgs a{};
+  a.base = luma.base; a.row_pitch = luma.row_pitch; a.frame_pitch = luma.frame_pitch;
+  a.w = w; a.h = h; a.threshold = threshold; a.partials = partials;
+  const dim3 grid(kLumaBlocks, n_frames), block(kBlock);
+  switch (elem) {
+    case ELEM_U8: hipLaunchKernelGGL((luma_stats_kernel<uint8_t>), grid, block, 0, stream, a); break;
+    case ELEM_U16: hipLaunchKernelGGL((luma_stats_kernel<uint16_t>), grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(luma_stats_finalize, dim3(n_frames), dim3(kBlock), 0, stream, partials, kLumaBlocks, out);
+  return hipGetLastError();
+}
+
+}  // namespace pqa

@@ -64,6 +64,8 @@ struct pqa_ctx {
   int ssim_tiles_n[3] = {};
   double ssim_norm[3] = {};
   double* records = nullptr;
+  unsigned long long* luma_part = nullptr;
+  unsigned long long* luma_out = nullptr;
   // motion continuity
   uint8_t* last_luma = nullptr;
   int64_t last_luma_pitch = 0;  // bytes
@@ -515,6 +517,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
       CREATE_TRY(dev_alloc(c, &c->ssim_part[p], (size_t)(c->ssim_tiles_n[p] ? c->ssim_tiles_n[p] : 1) * B));
     }
   }
+  CREATE_TRY(dev_alloc(c, &c->luma_part, (size_t)kLumaBlocks * 3 * B));
+  CREATE_TRY(dev_alloc(c, &c->luma_out, (size_t)3 * B));
   CREATE_TRY(dev_alloc(c, &c->records, (size_t)c->capacity * PQA_RECORD_DOUBLES));
   CREATE_HIP(hipMemsetAsync(c->records, 0, (size_t)c->capacity * PQA_RECORD_DOUBLES * sizeof(double), c->stream));
   CREATE_HIP(hipStreamSynchronize(c->stream));
@@ -683,6 +687,25 @@ int pqa_collect(pqa_ctx* c, int64_t first_index, int32_t count, double* records)
                         n * rec_bytes, hipMemcpyDeviceToHost));
     done += n;
     row = 0;
+  }
+  return PQA_OK;
+}
+
+int pqa_luma_stats_device(pqa_ctx* c, const void* luma, int64_t row_pitch, int64_t frame_pitch, int32_t n_frames,
+                          uint32_t threshold, uint64_t* out) {
+  if (!c) return PQA_EINVAL;
+  if (!luma || n_frames < 0 || (n_frames > 0 && !out)) return fail(c, PQA_EINVAL, "bad argument");
+  if (row_pitch % c->esize || frame_pitch % c->esize) return fail(c, PQA_EINVAL, "pitch is not a multiple of the sample size");
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int done = 0; done < n_frames;) {
+    const int n = n_frames - done < c->B ? n_frames - done : c->B;
+    const PlaneRun run{(const uint8_t*)luma + (int64_t)done * frame_pitch, row_pitch / c->esize, frame_pitch / c->esize};
+    HIPCHK(c, launch_luma_stats(c->stream, c->elem, run, n, c->pw[0], c->ph[0], threshold, c->luma_part, c->luma_out));
+    HIPCHK(c, hipMemcpyAsync(out + (size_t)done * 3, c->luma_out, (size_t)n * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    done += n;
   }
   return PQA_OK;
 }

@@ -98,6 +98,14 @@ class FeatureEngine:
         self._check(self.lib.pqa_submit_device(self._ctx, first_index, n_frames, C.byref(r), C.byref(d),
                                                prev_ref_luma_ptr or None, prev_row_pitch))
 
+    def luma_stats_resident(self, luma_ptr: int, row_pitch: int, frame_pitch: int, n_frames: int,
+                            threshold: int) -> np.ndarray:
+        """[n,3] uint64 {sum, sum of squares, count(sample > threshold)} per frame of a clip in HBM."""
+        out = np.zeros((n_frames, 3), np.uint64)
+        self._check(self.lib.pqa_luma_stats_device(self._ctx, luma_ptr, row_pitch, frame_pitch, n_frames,
+                                                   int(threshold), out.ctypes.data))
+        return out
+
     # -- results -----------------------------------------------------------------------------
     def collect(self, first_index: int, count: int) -> np.ndarray:
         out = np.zeros((count, N.RECORD_DOUBLES), np.float64)

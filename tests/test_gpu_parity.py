@@ -257,3 +257,26 @@ def test_result_ring_wraps():
                 out.append(eng.collect(i - 2, 3))
         out.append(eng.collect(9, 1))
     assert np.array_equal(np.concatenate(out), full)
+
+
+@pytest.mark.parametrize("bpc,w,h", [(8, 1920, 1080), (8, 333, 77), (10, 640, 360)])
+def test_luma_stats_exact(bpc, w, h):
+    """sum / sum of squares / count-above-threshold per frame: exact integers (bookend detection inputs)."""
+    import torch
+    n = 5
+    rng = np.random.default_rng(11)
+    peak = (1 << bpc) - 1
+    clip = rng.integers(0, peak + 1, (n, h, w)).astype(np.uint8 if bpc <= 8 else np.uint16)
+    clip[1] = peak  # a white frame
+    thr = 200 << (bpc - 8)
+    t = torch.from_numpy(clip.view(np.int16) if bpc > 8 else clip).cuda()
+    torch.cuda.synchronize()
+    es = 1 if bpc <= 8 else 2
+    with _engine(w, h, bit_depth=bpc, max_batch=2) as eng:
+        got = eng.luma_stats_resident(t.data_ptr(), w * es, w * h * es, n, thr)
+    c = clip.astype(np.int64)
+    want = np.stack([c.sum((1, 2)), (c * c).sum((1, 2)), (c > thr).sum((1, 2))], 1).astype(np.uint64)
+    assert np.array_equal(got, want)
+    from pqa2_amd import bookend
+    mean, std, ratio = bookend.brightness_from_stats(got, w * h)
+    assert bookend.starts_with_bookend(ratio) and ratio[1] == 1.0 and std[1] == 0.0

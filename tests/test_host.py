@@ -177,3 +177,35 @@ def test_analyzer_terminate_from_another_thread(tmp_path):
     assert ev["errors"] == ["VMAF analysis was terminated by user"] and ev["complete"] == []
     a._engine_factory = OracleEngine
     assert a.analyze_videos(rp, dp) is not None      # a new analysis re-arms, like the reference (:254)
+
+
+def test_bookend_rules_on_exact_stats():
+    from pqa2_amd import bookend
+    rng = np.random.default_rng(3)
+    frames = [np.full((40, 50), 250, np.uint8), rng.integers(0, 256, (40, 50), dtype=np.uint8),
+              np.clip(rng.normal(235, 30, (40, 50)), 0, 255).astype(np.uint8)]
+    thr = 200
+    stats = np.array([[int(f.sum()), int((f.astype(np.int64) ** 2).sum()), int((f > thr).sum())] for f in frames], np.uint64)
+    mean, std, ratio = bookend.brightness_from_stats(stats, 2000)
+    np.testing.assert_allclose(mean, [f.mean() for f in frames], rtol=1e-14)
+    np.testing.assert_allclose(std, [f.std() for f in frames], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ratio, [(f > thr).mean() for f in frames])
+    # the reference's rules, evaluated frame by frame the way its cv2 loop does
+    def ref_initial(f, wt, st, idx):
+        b, sd = np.mean(f), np.std(f)
+        return b > wt if idx < 2 else (b > wt and sd < st)
+
+    def ref_refined(f, t, st):
+        b, sd = np.mean(f), np.std(f)
+        if sd < st * 1.2:
+            return b > t * 0.95
+        if b > t:
+            return True
+        return b > t * 0.9 and np.sum(f > t) / f.size > 0.7
+    for idx in (0, 2):
+        assert bookend.is_white_initial(mean, std, 200, 30, idx).tolist() == [ref_initial(f, 200, 30, idx) for f in frames]
+    for t in (200, 220, 240):
+        st2 = np.array([[int(f.sum()), int((f.astype(np.int64) ** 2).sum()), int((f > t).sum())] for f in frames], np.uint64)
+        m2, s2, r2 = bookend.brightness_from_stats(st2, 2000)
+        assert bookend.is_white_refined(m2, s2, r2, t, 30).tolist() == [bool(ref_refined(f, t, 30)) for f in frames]
+    assert bookend.starts_with_bookend(ratio) and not bookend.starts_with_bookend(ratio[1:2])
