@@ -50,7 +50,7 @@ struct pqa_ctx {
   float inv_scale = 1.0f;
   int pw[3] = {0, 0, 0}, ph[3] = {0, 0, 0};
   int n_planes = 1;
-  int B = 8, capacity = 16384, k_sub = 1;
+  int B = 8, HB = 8, capacity = 16384, k_sub = 1;  // B: frames per launch; HB: frames per host-staging half
   Level vif_lv[4], adm_lv[4];
   double* vif_part[4] = {};
   int vif_tiles[4] = {};
@@ -347,8 +347,8 @@ int ensure_staging(pqa_ctx* c) {
   c->slot_bytes = off;
   for (int i = 0; i < 2; ++i) {
     Half& H = c->half[i];
-    HIPCHK(c, hipHostMalloc((void**)&H.pinned, c->slot_bytes * c->B, hipHostMallocDefault));
-    HIPCHK(c, hipMalloc((void**)&H.dev, c->slot_bytes * c->B));
+    HIPCHK(c, hipHostMalloc((void**)&H.pinned, c->slot_bytes * c->HB, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc((void**)&H.dev, c->slot_bytes * c->HB));
     HIPCHK(c, hipEventCreateWithFlags(&H.copied, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&H.computed, hipEventDisableTiming));
   }
@@ -405,7 +405,7 @@ void pqa_config_init(pqa_config* cfg, uint32_t width, uint32_t height) {
   cfg->n_planes = 1;
   cfg->chroma_hshift = cfg->chroma_vshift = 1;
   cfg->features = PQA_FEAT_VMAF;
-  cfg->max_batch = 8;
+  cfg->max_batch = 0;  // auto
   cfg->result_capacity = 16384;
   cfg->n_subsample = 1;
   cfg->vif_enhn_gain_limit = 100.0;
@@ -433,8 +433,15 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   if (!c) return fail(nullptr, PQA_ENOMEM, "out of host memory");
   c->cfg = *cfg;
   c->device = cfg->device;
-  c->B = cfg->max_batch ? (int)cfg->max_batch : 8;
+  if (cfg->max_batch) {
+    c->B = (int)cfg->max_batch;
+  } else {  // auto: about 512 MiB of luma per launch (2160p -> 32, 1080p -> 128), enough tiles to fill 256 CUs
+    const int64_t per_frame = 2ll * cfg->width * cfg->height * (cfg->bit_depth > 8 ? 2 : 1);
+    c->B = (int)((512ll << 20) / per_frame);
+    if (c->B < 8) c->B = 8;
+  }
   if (c->B > 256) c->B = 256;
+  c->HB = c->B < 8 ? c->B : 8;  // the host path is PCIe-bound: small pinned halves, same kernels
   c->capacity = cfg->result_capacity ? (int)cfg->result_capacity : 16384;
   if (c->capacity < c->B) c->capacity = c->B;
   c->k_sub = cfg->n_subsample > 1 ? (int)cfg->n_subsample : 1;
@@ -632,7 +639,7 @@ int pqa_submit(pqa_ctx* c, int64_t frame_index, const void* const ref_planes[3],
   HIPCHK(c, hipMemcpyAsync(H.dev + (size_t)c->pending * c->slot_bytes, slot, c->slot_bytes, hipMemcpyHostToDevice,
                            c->copy_stream));
   c->pending += 1;
-  if (c->pending == c->B) return flush_pending(c);
+  if (c->pending == c->HB) return flush_pending(c);
   return PQA_OK;
 }
 

@@ -15,7 +15,7 @@ from . import _native as N
 
 class FeatureEngine:
     def __init__(self, width: int, height: int, bit_depth: int = 8, n_planes: int = 1,
-                 chroma_shift=(1, 1), features: int = N.FEAT_VMAF, device: int = 0, max_batch: int = 8,
+                 chroma_shift=(1, 1), features: int = N.FEAT_VMAF, device: int = 0, max_batch: int = 0,
                  result_capacity: int = 16384, n_subsample: int = 1,
                  vif_enhn_gain_limit: float = 100.0, adm_enhn_gain_limit: float = 100.0):
         self.lib = N.load()

@@ -25,7 +25,7 @@ def _cap(v: np.ndarray, cap: float) -> np.ndarray:
 
 def score_files(reference_path: str, distorted_path: str, model: str | None = "vmaf_v0.6.1", *,
                 psnr: bool = True, ssim: bool = True, n_subsample: int = 1, device: int = 0,
-                rank: int = 0, world_size: int = 1, gather_device=None, max_batch: int = 8,
+                rank: int = 0, world_size: int = 1, gather_device=None, max_batch: int = 0,
                 progress=None, cancelled=None, engine_factory=None, raw_kwargs=None) -> ScoreResult | None:
     """Returns the ScoreResult on rank 0 (None on other ranks).  `progress(frames_done, frames_total)`
     is called as frames are submitted; `cancelled()` is polled between frames (True -> PqaCancelled)."""

@@ -24,7 +24,7 @@ def main(argv=None) -> int:
     ap.add_argument("--psnr-log")
     ap.add_argument("--ssim-log")
     ap.add_argument("--n-subsample", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=0)
     a = ap.parse_args(argv)
 
     from . import report

@@ -99,7 +99,7 @@ class VMAFAnalyzer(QObject):
         # extensions (defaults reproduce the reference's behaviour)
         self.device = 0                       # HIP device ordinal for single-process runs
         self.gpus = 1                         # >1: frame-sharded child job, one process per GPU
-        self.max_batch = 8
+        self.max_batch = 0                    # 0: the library sizes launches itself
         self.last_fps = 0.0
         self._engine_factory = None           # tests inject a stand-in; product code leaves it None
 
