@@ -39,7 +39,22 @@ class SvmModel:
         return [feature_key(n) for n in self.feature_names]
 
     def predict(self, feats: np.ndarray, enable_transform: bool = False) -> np.ndarray:
-        """feats [n, n_features] in model order -> scores [n]."""
+        """feats [n, n_features] in model order -> scores [n].  Long clips (the gathered records of an
+        8-GPU job land on one rank) are scored in fixed 512-frame blocks on a few threads (numpy releases the
+        GIL inside matmul / exp)."""
+        feats = np.asarray(feats, np.float64)
+        n = feats.shape[0]
+        block = 512   # fixed, so a frame's score depends on n only -- not on the thread or GPU count
+        if n <= block:
+            return self._predict_block(feats, enable_transform)
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        starts = list(range(0, n, block))
+        with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1, len(starts)))) as ex:
+            parts = list(ex.map(lambda s0: self._predict_block(feats[s0:s0 + block], enable_transform), starts))
+        return np.concatenate(parts)
+
+    def _predict_block(self, feats: np.ndarray, enable_transform: bool = False) -> np.ndarray:
         x = np.asarray(feats, np.float64) * self.slopes[1:] + self.intercepts[1:]
         # ||x - sv||^2 = ||x||^2 + ||sv||^2 - 2 x.sv : one small GEMM instead of an [n, n_sv, 6] temporary
         # (f64; features and SVs are O(1), so the cancellation costs ~1e-15 -- far below libvmaf's %.6f)
