@@ -39,20 +39,13 @@ class SvmModel:
         return [feature_key(n) for n in self.feature_names]
 
     def predict(self, feats: np.ndarray, enable_transform: bool = False) -> np.ndarray:
-        """feats [n, n_features] in model order -> scores [n].  Long clips (the gathered records of an
-        8-GPU job land on one rank) are scored in fixed 512-frame blocks on a few threads (numpy releases the
-        GIL inside matmul / exp)."""
+        """feats [n, n_features] in model order -> scores [n]."""
         feats = np.asarray(feats, np.float64)
         n = feats.shape[0]
-        block = 512   # fixed, so a frame's score depends on n only -- not on the thread or GPU count
+        block = 512   # fixed cache-sized blocks: a frame's score does not depend on how many frames ride along
         if n <= block:
             return self._predict_block(feats, enable_transform)
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-        starts = list(range(0, n, block))
-        with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1, len(starts)))) as ex:
-            parts = list(ex.map(lambda s0: self._predict_block(feats[s0:s0 + block], enable_transform), starts))
-        return np.concatenate(parts)
+        return np.concatenate([self._predict_block(feats[s0:s0 + block], enable_transform) for s0 in range(0, n, block)])
 
     def _predict_block(self, feats: np.ndarray, enable_transform: bool = False) -> np.ndarray:
         x = np.asarray(feats, np.float64) * self.slopes[1:] + self.intercepts[1:]

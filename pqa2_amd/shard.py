@@ -63,3 +63,23 @@ def score_sharded(n_frames: int, world_size: int, rank: int, feature_fn, device=
     a, b = shard_bounds(n_frames, world_size, rank)
     local = feature_fn(a, b, a - 1 if a > 0 else None) if b > a else np.zeros((0, RECORD_DOUBLES))
     return gather_records(np.asarray(local, np.float64), n_frames, world_size, rank, device)
+
+
+def gather_vector(local: np.ndarray, n_frames: int, world_size: int, rank: int, device=None) -> np.ndarray:
+    """All-gather one float64 per frame (e.g. the per-frame scores each rank predicted for its own chunk)."""
+    if world_size == 1:
+        return np.asarray(local, np.float64)
+    import torch
+    import torch.distributed as dist
+    rows = -(-n_frames // world_size)
+    tile = np.zeros(rows, np.float64)
+    a, b = shard_bounds(n_frames, world_size, rank)
+    tile[: b - a] = local
+    t = torch.from_numpy(tile)
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty(world_size * rows, dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    full = out.cpu().numpy().reshape(world_size, rows)
+    return np.concatenate([full[r, : shard_bounds(n_frames, world_size, r)[1] - shard_bounds(n_frames, world_size, r)[0]]
+                           for r in range(world_size)])

@@ -61,3 +61,25 @@ def test_sharded_equals_single_process(tmp_path, world):
     assert got.shape == single.shape
     assert np.array_equal(got.view(np.uint64), single.view(np.uint64))   # incl. motion across the shard seams
     assert np.all(got[1:, 16] > 0) and got[0, 16] == 0
+
+
+def _vec_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 11
+    a, b = shard.shard_bounds(n, world, rank)
+    full = shard.gather_vector(np.arange(a, b, dtype=np.float64) * 1.5, n, world, rank)
+    if rank == 1:
+        np.save(out_path, full)
+    dist.destroy_process_group()
+
+
+def test_gather_vector_two_ranks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "v.npy")
+    mp.spawn(_vec_worker, args=(2, port, out), nprocs=2, join=True)
+    assert np.array_equal(np.load(out), np.arange(11) * 1.5)
