@@ -121,7 +121,10 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
       // Input rows stream through in groups of G: the loads of group g+1 are in flight while group g is
       // consumed; sched_barrier keeps hipcc from hoisting all 2*NIN loads (and their r*r, d*d, r*d) to
       // the top, which costs ~120 VGPRs and a wave of occupancy.
-      constexpr int G = 4, NG = (NIN + G - 1) / G;
+#ifndef PQA_VIF_G
+#define PQA_VIF_G 12   /* rows per load group: 2 groups at N = 17 (swept 4/6/8/12 on the box) */
+#endif
+      constexpr int G = PQA_VIF_G, NG = (NIN + G - 1) / G;
       T rn[G], dn[G];
       auto issue = [&](int g) {
 #pragma unroll
@@ -265,15 +268,15 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
       if (s2.x < eps) { g.x = 0.0f; sv.x = 0.0f; }
       if (s2.y < eps) { g.y = 0.0f; sv.y = 0.0f; }
       sv = f2{fmaxf(sv.x, eps), fmaxf(sv.y, eps)};
-      g = f2{fminf(g.x, a.gain_limit), fminf(g.y, a.gain_limit)};
+      // clamp g to [0, gain_limit] with one v_med3_f32: the upper bound is vif_enhn_gain_limit, the lower
+      // bound makes g*g = 0 when sigma12 < 0, i.e. num_val = log2(1) = 0 -- libvmaf's `if (sigma12 < 0) num_val = 0`
+      g = f2{__builtin_amdgcn_fmed3f(g.x, 0.0f, a.gain_limit), __builtin_amdgcn_fmed3f(g.y, 0.0f, a.gain_limit)};
       const f2 svn = sv + f2{sigma_nsq, sigma_nsq};
       const f2 narg = __builtin_elementwise_fma(g * g * s1, f2{fast_rcp(svn.x), fast_rcp(svn.y)}, f2{1.0f, 1.0f});
       const f2 darg = __builtin_elementwise_fma(s1, f2{1.0f / sigma_nsq, 1.0f / sigma_nsq}, f2{1.0f, 1.0f});
       f2 nv = f2{fast_log2(narg.x), fast_log2(narg.y)};
       f2 dv = f2{fast_log2(darg.x), fast_log2(darg.y)};
       const f2 low = __builtin_elementwise_fma(s2, f2{-sigma_max_inv, -sigma_max_inv}, f2{1.0f, 1.0f});
-      if (s12.x < 0.0f) nv.x = 0.0f;
-      if (s12.y < 0.0f) nv.y = 0.0f;
       if (s1.x < sigma_nsq) { nv.x = low.x; dv.x = 1.0f; }
       if (s1.y < sigma_nsq) { nv.y = low.y; dv.y = 1.0f; }
       const f2 m = mrow2 * f2{mcol, mcol};
