@@ -35,20 +35,30 @@ struct AdmArgs {
   double* partials;
 };
 
-constexpr int TW = kAdmTileW, TH = kAdmTileH, GW = TW + 2, GH = TH + 2;
+constexpr int TW = kAdmTileW, TH = kAdmTileH, GW = TW + 2, GH = TH + 2, NRP = GH / 2;
 constexpr int VC = 2 * GW + 2, VP = 128;  // vertical-pass columns (126) / LDS pitch (float2)
-static_assert(VC <= 128 && VC <= VP, "one column per lane, two strips per workgroup");
+static_assert(VC <= 128 && VC <= VP && GH % 2 == 0 && GW <= 64, "one column per lane, rows in pairs");
 constexpr int SROWS = GH / 2;             // output rows per vertical strip (2 strips)
 constexpr int NIN = 2 * SROWS + 2;        // input rows per strip
-constexpr int NROUND = 5;                 // phase 2/3 rounds: 4.5 x (64 cols x 4 rows) + halo columns
-constexpr int GP = GW + 3;                // pitch of the masking-signal array
+constexpr int NROUND = NRP / 4;           // phase 2/3 rounds: 4 waves x 1 row pair each per round
+constexpr int GP = 68;                    // pitch of the masking-signal array
 
 __device__ __forceinline__ f2 splat(float c) { return f2{c, c}; }
+__device__ __forceinline__ f2 rcp2(f2 x) { return f2{fast_rcp(x.x), fast_rcp(x.y)}; }
+__device__ __forceinline__ f2 clamp01_2(f2 k) {
+  return f2{__builtin_amdgcn_fmed3f(k.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(k.y, 0.0f, 1.0f)};
+}
+__device__ __forceinline__ f2 med3_2(f2 a, f2 b, f2 c) {
+  return f2{__builtin_amdgcn_fmed3f(a.x, b.x, c.x), __builtin_amdgcn_fmed3f(a.y, b.y, c.y)};
+}
 
+// Layout note.  Everything after the vertical DWT works on float2 = {row 2p, row 2p+1}: two vertically
+// adjacent coefficients of the same column.  The vertical pass produces {ref, dis} pairs (one packed FMA
+// per tap for both images) and re-pairs them by rows when it stores to LDS, so the horizontal DWT reads
+// natural row pairs and the whole decouple / CSF / masking chain runs packed on two coefficients.
 template <typename T>
-__global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
-  __shared__ f2 Vlo[GH][VP];    // vertical low-pass  {ref, dis}
-  __shared__ f2 Vhi[GH][VP];    // vertical high-pass {ref, dis}
+__global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
+  __shared__ f2 V[4][NRP][VP];  // 0 lo(ref) 1 hi(ref) 2 lo(dis) 3 hi(dis); {row 2p, row 2p+1}
   __shared__ float G[GH][GP];   // masking signal: sum over orientations of |csf(a)| / 30
   __shared__ double red[24];
 
@@ -69,168 +79,188 @@ __global__ __launch_bounds__(kBlock, 3) void adm_scale_kernel(const AdmArgs a) {
   const rsrc_t rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d * (unsigned)sizeof(T));
 
   // ---- phase 1: vertical DWT -------------------------------------------------------------------
-  // items: VC (126) columns x 2 strips of 9 output rows: one pass, every wave busy, rows wave-uniform
+  // VC (126) columns x 2 strips of 8 output rows: one pass, every wave busy, rows wave-uniform
   {
     const int col = tid & 127;
     const int strip = __builtin_amdgcn_readfirstlane(tid >> 7);
     if (col < VC) {
-    const unsigned gx = (unsigned)mirror1(2 * cx0 - 3 + col, a.w);
-    f2 x[NIN];
+      const unsigned gx = (unsigned)mirror1(2 * cx0 - 3 + col, a.w);
+      f2 x[NIN];
 #pragma unroll
-    for (int j = 0; j < NIN; ++j) {
-      const unsigned gy = (unsigned)mirror1(2 * cy0 - 3 + 2 * SROWS * strip + j, a.h);
-      const T r = buf_load<T>(rsrc_r, gx, gy * pitch_r);  // row offset rides in an SGPR
-      const T d = buf_load<T>(rsrc_d, gx, gy * pitch_d);
-      x[j] = PixIO<T>::pair(r, d, a.inv_scale);
-    }
+      for (int j = 0; j < NIN; ++j) {
+        const unsigned gy = (unsigned)mirror1(2 * cy0 - 3 + 2 * SROWS * strip + j, a.h);
+        const T r = buf_load<T>(rsrc_r, gx, gy * pitch_r);  // row offset rides in an SGPR
+        const T d = buf_load<T>(rsrc_d, gx, gy * pitch_d);
+        x[j] = PixIO<T>::pair(r, d, a.inv_scale);
+      }
 #pragma unroll
-    for (int o = 0; o < SROWS; ++o) {
-      const int lr = strip * SROWS + o;
-      // taps accumulate in libvmaf's order: ((c0*s0 + c1*s1) + c2*s2) + c3*s3
-      f2 vl = splat(lo0) * x[2 * o], vh = splat(hi0) * x[2 * o];
-      vl = __builtin_elementwise_fma(splat(lo1), x[2 * o + 1], vl);
-      vh = __builtin_elementwise_fma(splat(hi1), x[2 * o + 1], vh);
-      vl = __builtin_elementwise_fma(splat(lo2), x[2 * o + 2], vl);
-      vh = __builtin_elementwise_fma(splat(hi2), x[2 * o + 2], vh);
-      vl = __builtin_elementwise_fma(splat(lo3), x[2 * o + 3], vl);
-      vh = __builtin_elementwise_fma(splat(hi3), x[2 * o + 3], vh);
-      Vlo[lr][col] = vl;
-      Vhi[lr][col] = vh;
-    }
+      for (int p = 0; p < SROWS / 2; ++p) {
+        f2 vl[2], vh[2];  // {ref, dis} for rows 2p and 2p+1 of the strip
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int o = 2 * p + e;
+          // taps accumulate in libvmaf's order: ((c0*s0 + c1*s1) + c2*s2) + c3*s3
+          f2 l = splat(lo0) * x[2 * o], h = splat(hi0) * x[2 * o];
+          l = __builtin_elementwise_fma(splat(lo1), x[2 * o + 1], l);
+          h = __builtin_elementwise_fma(splat(hi1), x[2 * o + 1], h);
+          l = __builtin_elementwise_fma(splat(lo2), x[2 * o + 2], l);
+          h = __builtin_elementwise_fma(splat(hi2), x[2 * o + 2], h);
+          l = __builtin_elementwise_fma(splat(lo3), x[2 * o + 3], l);
+          h = __builtin_elementwise_fma(splat(hi3), x[2 * o + 3], h);
+          vl[e] = l;
+          vh[e] = h;
+        }
+        const int rp = strip * (SROWS / 2) + p;
+        V[0][rp][col] = f2{vl[0].x, vl[1].x};
+        V[1][rp][col] = f2{vh[0].x, vh[1].x};
+        V[2][rp][col] = f2{vl[0].y, vl[1].y};
+        V[3][rp][col] = f2{vh[0].y, vh[1].y};
+      }
     }
   }
   __syncthreads();
 
-  // ---- phase 2: horizontal DWT, decouple, CSF ------------------------------------------------
-  // grid of (GW x GH) coefficients incl. halo: rounds 0..3 take columns 1..64 x rows 4r..4r+3, round 4
-  // takes rows 16,17 of those columns (threads 0..127) and the two halo columns x 18 rows (threads 128..163)
+  // ---- phase 2: horizontal DWT, decouple, CSF on row pairs ----------------------------------------
+  // lane <-> halo'd column (62 of 64 used), wave + 4*round <-> row pair
   const float cos_1deg_sq = 0.99969541350954788f;  // cos(pi/180)^2
   const float eps = 1e-30f;
-  float xs[NROUND][3];
-  float den_h = 0.0f, den_v = 0.0f, den_d = 0.0f;
-  unsigned acc_mask = 0;
+  const int lcx = tid & 63;
+  const bool have = lcx < GW;
+  const int lcxs = have ? lcx : 0;
+  const int cx = cx0 - 1 + lcxs;
+  const bool col_valid = have && cx >= 0 && cx < a.ow;
+  const bool col_inner = col_valid && lcxs >= 1 && lcxs <= TW;
+  const bool col_win = col_inner && cx >= a.left && cx < a.right;
+  f2 xs[NROUND][3];
+  f2 mwin[NROUND];
+  f2 den_h = f2{0.0f, 0.0f}, den_v = den_h, den_d = den_h;
 #pragma unroll
   for (int k = 0; k < NROUND; ++k) {
-    int lcx, lcy;
-    bool have = true;
-    if (k < 4) {
-      lcx = 1 + (tid & 63);
-      lcy = 4 * k + (tid >> 6);
-      have = lcx <= TW;
-    } else if (tid < 128) {
-      lcx = 1 + (tid & 63);
-      lcy = 16 + (tid >> 6);
-      have = lcx <= TW;
-    } else {
-      const int t = tid - 128;
-      have = t < 2 * GH;
-      lcx = (t & 1) ? GW - 1 : 0;
-      lcy = have ? (t >> 1) : 0;
+    const int rp = (tid >> 6) + 4 * k;
+    const int lcyA = 2 * rp, cyA = cy0 - 1 + lcyA, cyB = cyA + 1;
+    f2 s[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4* p = reinterpret_cast<const f4*>(&V[q][rp][2 * lcxs]);
+      const f4 v01 = p[0], v23 = p[1];
+      s[q][0] = f2{v01.x, v01.y}; s[q][1] = f2{v01.z, v01.w};
+      s[q][2] = f2{v23.x, v23.y}; s[q][3] = f2{v23.z, v23.w};
     }
-    // Straight-line code from here: every lane computes its coefficient (positions outside the band or
-    // the accumulation window hold finite mirrored data) and validity enters as selects / 0-1 weights.
-    // hipcc turns the reference's nested ifs into exec-mask branches otherwise (7 per coefficient).
-    if (!have) { lcx = 0; lcy = 0; }
-    const int cx = cx0 - 1 + lcx, cy = cy0 - 1 + lcy;
-    const bool valid = have && cx >= 0 && cx < a.ow && cy >= 0 && cy < a.oh;
-    const f4* pl = reinterpret_cast<const f4*>(&Vlo[lcy][2 * lcx]);
-    const f4* ph = reinterpret_cast<const f4*>(&Vhi[lcy][2 * lcx]);
-    const f4 l01 = pl[0], l23 = pl[1], h01 = ph[0], h23 = ph[1];
-    const f2 l0 = f2{l01.x, l01.y}, l1 = f2{l01.z, l01.w}, l2 = f2{l23.x, l23.y}, l3 = f2{l23.z, l23.w};
-    const f2 h0 = f2{h01.x, h01.y}, h1 = f2{h01.z, h01.w}, h2 = f2{h23.x, h23.y}, h3 = f2{h23.z, h23.w};
-#define PQA_DWT(c0, c1, c2, c3, s0, s1, s2, s3)                                                        \
-  __builtin_elementwise_fma(splat(c3), s3,                                                             \
-                            __builtin_elementwise_fma(splat(c2), s2, __builtin_elementwise_fma(splat(c1), s1, splat(c0) * s0)))
-    const f2 ba = PQA_DWT(lo0, lo1, lo2, lo3, l0, l1, l2, l3);  // {ref, dis} approximation
-    const f2 bv = PQA_DWT(hi0, hi1, hi2, hi3, l0, l1, l2, l3);  // vertical   (lo-v, hi-h)
-    const f2 bh = PQA_DWT(lo0, lo1, lo2, lo3, h0, h1, h2, h3);  // horizontal (hi-v, lo-h)
-    const f2 bd = PQA_DWT(hi0, hi1, hi2, hi3, h0, h1, h2, h3);  // diagonal
+#define PQA_DWT(c0, c1, c2, c3, t)                                                                        \
+  __builtin_elementwise_fma(splat(c3), t[3],                                                              \
+                            __builtin_elementwise_fma(splat(c2), t[2], __builtin_elementwise_fma(splat(c1), t[1], splat(c0) * t[0])))
+    const f2 ra = PQA_DWT(lo0, lo1, lo2, lo3, s[0]);  // reference approximation, rows {A, B}
+    const f2 ov = PQA_DWT(hi0, hi1, hi2, hi3, s[0]);  // vertical   (lo-v, hi-h)
+    const f2 oh = PQA_DWT(lo0, lo1, lo2, lo3, s[1]);  // horizontal (hi-v, lo-h)
+    const f2 od = PQA_DWT(hi0, hi1, hi2, hi3, s[1]);  // diagonal
+    const f2 da = PQA_DWT(lo0, lo1, lo2, lo3, s[2]);
+    const f2 tv = PQA_DWT(hi0, hi1, hi2, hi3, s[2]);
+    const f2 th = PQA_DWT(lo0, lo1, lo2, lo3, s[3]);
+    const f2 td = PQA_DWT(hi0, hi1, hi2, hi3, s[3]);
 #undef PQA_DWT
-    const bool inner = valid && lcx >= 1 && lcx <= TW && lcy >= 1 && lcy <= TH;
-    if (inner && a.ll_ref) {
-      const unsigned off_r = (unsigned)cy * (unsigned)a.ll_row_pitch_r + (unsigned)cx;
-      const unsigned off_d = (unsigned)cy * (unsigned)a.ll_row_pitch_d + (unsigned)cx;
-      (a.ll_ref + (int64_t)fr * a.ll_frame_pitch_r)[off_r] = ba.x;
-      (a.ll_dis + (int64_t)fr * a.ll_frame_pitch_d)[off_d] = ba.y;
+    const bool vA = col_valid && cyA >= 0 && cyA < a.oh, vB = col_valid && cyB >= 0 && cyB < a.oh;
+    const bool iA = col_inner && lcyA >= 1 && cyA < a.oh;                    // lcyA <= TH always (lcyA <= GH-2)
+    const bool iB = col_inner && lcyA + 1 <= TH && cyB >= 0 && cyB < a.oh;   // lcyA + 1 >= 1 always
+    if (a.ll_ref) {
+      float* lr = a.ll_ref + (int64_t)fr * a.ll_frame_pitch_r;
+      float* ld = a.ll_dis + (int64_t)fr * a.ll_frame_pitch_d;
+      if (iA) {
+        lr[(unsigned)cyA * (unsigned)a.ll_row_pitch_r + (unsigned)cx] = ra.x;
+        ld[(unsigned)cyA * (unsigned)a.ll_row_pitch_d + (unsigned)cx] = da.x;
+      }
+      if (iB) {
+        lr[(unsigned)cyB * (unsigned)a.ll_row_pitch_r + (unsigned)cx] = ra.y;
+        ld[(unsigned)cyB * (unsigned)a.ll_row_pitch_d + (unsigned)cx] = da.y;
+      }
     }
-    const float oh = bh.x, ov = bv.x, od = bd.x, th = bh.y, tv = bv.y, td = bd.y;
     // decouple: k = clamp(t / (o + eps), 0, 1) via v_rcp_f32 + one Newton step.  o + eps is either 1e-30
     // (o == 0) or |o| >~ 1e-9 (an f32 DWT of bounded samples cannot produce a smaller non-zero value), so the
     // reciprocal stays finite and no NaN can form.
-    const float xh = oh + eps, xv = ov + eps, xd = od + eps;
-    const float rch = fast_rcp(xh), rcv = fast_rcp(xv), rcd = fast_rcp(xd);
-    float kh = th * rch, kv = tv * rcv, kd = td * rcd;
-    kh = __builtin_amdgcn_fmed3f(fmaf(fmaf(-kh, xh, th), rch, kh), 0.0f, 1.0f);
-    kv = __builtin_amdgcn_fmed3f(fmaf(fmaf(-kv, xv, tv), rcv, kv), 0.0f, 1.0f);
-    kd = __builtin_amdgcn_fmed3f(fmaf(fmaf(-kd, xd, td), rcd, kd), 0.0f, 1.0f);
-    float rh = kh * oh, rv = kv * ov, rd = kd * od;
-    const float ot_dp = oh * th + ov * tv;
-    const float o_mag_sq = oh * oh + ov * ov, t_mag_sq = th * th + tv * tv;
-    const bool angle_flag = (ot_dp >= 0.0f) && (ot_dp * ot_dp >= cos_1deg_sq * o_mag_sq * t_mag_sq);
+    const f2 e2 = splat(eps);
+    const f2 xh = oh + e2, xv = ov + e2, xd = od + e2;
+    const f2 rch = rcp2(xh), rcv = rcp2(xv), rcd = rcp2(xd);
+    f2 kh = th * rch, kv = tv * rcv, kd = td * rcd;
+    kh = clamp01_2(__builtin_elementwise_fma(__builtin_elementwise_fma(-kh, xh, th), rch, kh));
+    kv = clamp01_2(__builtin_elementwise_fma(__builtin_elementwise_fma(-kv, xv, tv), rcv, kv));
+    kd = clamp01_2(__builtin_elementwise_fma(__builtin_elementwise_fma(-kd, xd, td), rcd, kd));
+    f2 rh = kh * oh, rv = kv * ov, rd = kd * od;
+    const f2 ot_dp = __builtin_elementwise_fma(ov, tv, oh * th);
+    const f2 o_mag_sq = __builtin_elementwise_fma(ov, ov, oh * oh), t_mag_sq = __builtin_elementwise_fma(tv, tv, th * th);
+    const f2 lhs = ot_dp * ot_dp, rhs = splat(cos_1deg_sq) * o_mag_sq * t_mag_sq;
+    const bool angA = (ot_dp.x >= 0.0f) && (lhs.x >= rhs.x), angB = (ot_dp.y >= 0.0f) && (lhs.y >= rhs.y);
     // enhancement-gain limit under the angle test: r > 0 -> min(r*limit, t); r < 0 -> max(r*limit, t);
     // r == 0 stays.  Because r = clamp(t/o, 0, 1) * o lies between 0 and t and limit >= 1, all three cases
     // are the median of {r, r*limit, t}: one v_med3_f32 (differs from the branchy form only when k*o
     // rounds 1 ulp past t).
-    rh = angle_flag ? __builtin_amdgcn_fmed3f(rh, rh * a.gain_limit, th) : rh;
-    rv = angle_flag ? __builtin_amdgcn_fmed3f(rv, rv * a.gain_limit, tv) : rv;
-    rd = angle_flag ? __builtin_amdgcn_fmed3f(rd, rd * a.gain_limit, td) : rd;
+    const f2 gl = splat(a.gain_limit);
+    const f2 mh = med3_2(rh, rh * gl, th), mv = med3_2(rv, rv * gl, tv), md = med3_2(rd, rd * gl, td);
+    rh = f2{angA ? mh.x : rh.x, angB ? mh.y : rh.y};
+    rv = f2{angA ? mv.x : rv.x, angB ? mv.y : rv.y};
+    rd = f2{angA ? md.x : rd.x, angB ? md.y : rd.y};
     // CSF of the additive image; adm_cm_s sums the 3x3 boxes per orientation and then over
     // orientations -- summing over orientations first is the same value up to float rounding
-    const float g = (1.0f / 30.0f) * (fabsf(a.rf_hv * (th - rh)) + fabsf(a.rf_hv * (tv - rv)) + fabsf(a.rf_d * (td - rd)));
-    const bool in_win = inner && cx >= a.left && cx < a.right && cy >= a.top && cy < a.bottom;
-    const float mw = in_win ? 1.0f : 0.0f;
-    acc_mask |= in_win ? (1u << k) : 0u;
-    xs[k][0] = fabsf(rh * a.rf_hv);
-    xs[k][1] = fabsf(rv * a.rf_hv);
-    xs[k][2] = fabsf(rd * a.rf_d);
-    const float vh = fabsf(oh) * a.rf_hv, vv = fabsf(ov) * a.rf_hv, vd = fabsf(od) * a.rf_d;
-    den_h = fmaf(mw * vh, vh * vh, den_h);
-    den_v = fmaf(mw * vv, vv * vv, den_v);
-    den_d = fmaf(mw * vd, vd * vd, den_d);
-    if (have) G[lcy][lcx] = valid ? g : 0.0f;
+    const f2 ah = splat(a.rf_hv) * (th - rh), av = splat(a.rf_hv) * (tv - rv), ad = splat(a.rf_d) * (td - rd);
+    const float gA = (1.0f / 30.0f) * (fabsf(ah.x) + fabsf(av.x) + fabsf(ad.x));
+    const float gB = (1.0f / 30.0f) * (fabsf(ah.y) + fabsf(av.y) + fabsf(ad.y));
+    const bool wA = iA && col_win && cyA >= a.top && cyA < a.bottom;
+    const bool wB = iB && col_win && cyB >= a.top && cyB < a.bottom;
+    const f2 mw = f2{wA ? 1.0f : 0.0f, wB ? 1.0f : 0.0f};
+    mwin[k] = mw;
+    xs[k][0] = rh * splat(a.rf_hv);   // signed; |.| is applied where it is used
+    xs[k][1] = rv * splat(a.rf_hv);
+    xs[k][2] = rd * splat(a.rf_d);
+    const f2 uh = oh * splat(a.rf_hv), uv = ov * splat(a.rf_hv), ud = od * splat(a.rf_d);
+    const f2 qh = mw * (uh * uh), qv = mw * (uv * uv), qd = mw * (ud * ud);
+    den_h = f2{fmaf(qh.x, fabsf(uh.x), den_h.x), fmaf(qh.y, fabsf(uh.y), den_h.y)};
+    den_v = f2{fmaf(qv.x, fabsf(uv.x), den_v.x), fmaf(qv.y, fabsf(uv.y), den_v.y)};
+    den_d = f2{fmaf(qd.x, fabsf(ud.x), den_d.x), fmaf(qd.y, fabsf(ud.y), den_d.y)};
+    if (have) {
+      G[lcyA][lcx] = vA ? gA : 0.0f;
+      G[lcyA + 1][lcx] = vB ? gB : 0.0f;
+    }
   }
   __syncthreads();
 
-  // ---- phase 3: contrast masking -------------------------------------------------------------
-  float num_h = 0.0f, num_v = 0.0f, num_d = 0.0f;
+  // ---- phase 3: contrast masking on row pairs ------------------------------------------------------
+  f2 num_h = f2{0.0f, 0.0f}, num_v = num_h, num_d = num_h;
+  {
+    // band-level mirror of the 3x3 neighbourhood (only bites when the window touches the border)
+    const int lx0 = have ? mirror1(cx - 1, a.ow) - (cx0 - 1) : 0, lx2 = have ? mirror1(cx + 1, a.ow) - (cx0 - 1) : 0;
 #pragma unroll
-  for (int k = 0; k < NROUND - 1; ++k) {  // inner coefficients only live in rounds 0..4; round 4 rows 16 only
-    if (acc_mask & (1u << k)) {
-      const int lcx = 1 + (tid & 63), lcy = 4 * k + (tid >> 6);
-      const int cx = cx0 - 1 + lcx, cy = cy0 - 1 + lcy;
-      // band-level mirror of the 3x3 neighbourhood (only bites when the window touches the border)
-      const int ly0 = mirror1(cy - 1, a.oh) - (cy0 - 1), ly2 = mirror1(cy + 1, a.oh) - (cy0 - 1);
-      const int lx0 = mirror1(cx - 1, a.ow) - (cx0 - 1), lx2 = mirror1(cx + 1, a.ow) - (cx0 - 1);
-      const float c = G[lcy][lcx];
-      float thr = G[ly0][lx0] + G[ly0][lcx] + G[ly0][lx2];
-      thr += G[lcy][lx0] + c + G[lcy][lx2];
-      thr += G[ly2][lx0] + G[ly2][lcx] + G[ly2][lx2];
-      thr += c;
-      float xh = xs[k][0] - thr, xv = xs[k][1] - thr, xd = xs[k][2] - thr;
-      xh = fmaxf(xh, 0.0f);
-      xv = fmaxf(xv, 0.0f);
-      xd = fmaxf(xd, 0.0f);
-      num_h += xh * xh * xh;
-      num_v += xv * xv * xv;
-      num_d += xd * xd * xd;
+    for (int k = 0; k < NROUND; ++k) {
+      const int rp = (tid >> 6) + 4 * k;
+      const int lcyA = 2 * rp, cyA = cy0 - 1 + lcyA;
+      // rows A-1, A, B, B+1 of the masking signal, clamped into the tile's halo'd grid (the clamped ones
+      // belong to elements that are not inner and carry weight 0)
+      int ly[4] = {mirror1(cyA - 1, a.oh) - (cy0 - 1), lcyA, lcyA + 1, mirror1(cyA + 2, a.oh) - (cy0 - 1)};
+      ly[0] = min(max(ly[0], 0), GH - 1);
+      ly[3] = min(max(ly[3], 0), GH - 1);
+      float rs[4], c[2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m = G[ly[j]][lcxs];
+        rs[j] = G[ly[j]][lx0] + m + G[ly[j]][lx2];
+        if (j == 1) c[0] = m;
+        if (j == 2) c[1] = m;
+      }
+      // interior: A's lower neighbour is B and B's upper neighbour is A.  At the band's last row the mirror
+      // of A+1 is A itself; at the band's first row (B = 0, A above the band) the mirror of B-1 is B+1.
+      const float downA = (cyA + 1 < a.oh) ? rs[2] : rs[1];
+      const float upB = (cyA >= 0) ? rs[1] : rs[3];
+      const f2 thr = f2{(rs[0] + rs[1] + downA) + c[0], (upB + rs[2] + rs[3]) + c[1]};
+      const f2 mw = mwin[k];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        f2 x = f2{fmaxf(fabsf(xs[k][t].x) - thr.x, 0.0f), fmaxf(fabsf(xs[k][t].y) - thr.y, 0.0f)};
+        const f2 x3 = (mw * x) * (x * x);
+        if (t == 0) num_h += x3;
+        if (t == 1) num_v += x3;
+        if (t == 2) num_d += x3;
+      }
     }
   }
-  if (acc_mask & (1u << 4)) {  // row 16 of the halo'd grid (last inner row), threads 0..63
-    const int lcx = 1 + (tid & 63), lcy = 16 + (tid >> 6);
-    const int cx = cx0 - 1 + lcx, cy = cy0 - 1 + lcy;
-    const int ly0 = mirror1(cy - 1, a.oh) - (cy0 - 1), ly2 = mirror1(cy + 1, a.oh) - (cy0 - 1);
-    const int lx0 = mirror1(cx - 1, a.ow) - (cx0 - 1), lx2 = mirror1(cx + 1, a.ow) - (cx0 - 1);
-    const float c = G[lcy][lcx];
-    float thr = G[ly0][lx0] + G[ly0][lcx] + G[ly0][lx2];
-    thr += G[lcy][lx0] + c + G[lcy][lx2];
-    thr += G[ly2][lx0] + G[ly2][lcx] + G[ly2][lx2];
-    thr += c;
-    const float xh = fmaxf(xs[4][0] - thr, 0.0f), xv = fmaxf(xs[4][1] - thr, 0.0f), xd = fmaxf(xs[4][2] - thr, 0.0f);
-    num_h += xh * xh * xh;
-    num_v += xv * xv * xv;
-    num_d += xd * xd * xd;
-  }
-  const float part[6] = {num_h, num_v, num_d, den_h, den_v, den_d};
+  const float part[6] = {num_h.x + num_h.y, num_v.x + num_v.y, num_d.x + num_d.y,
+                         den_h.x + den_h.y, den_v.x + den_v.y, den_d.x + den_d.y};
   double v[6];
   block_sum_f32<6>(part, v, red);
   if (tid == 0) {

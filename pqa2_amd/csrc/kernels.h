@@ -38,7 +38,7 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
                            MutPlaneRun next_ref, MutPlaneRun next_dis);
 
 // ---- ADM ------------------------------------------------------------------------------------
-constexpr int kAdmTileW = 60, kAdmTileH = 16;  // 2*(60+2)+2 = 126 input columns: one per lane
+constexpr int kAdmTileW = 60, kAdmTileH = 14;  // 126 input columns (one per lane), 16 halo'd rows = 8 row pairs
 inline int adm_tiles_x(int band_w) { return (band_w + kAdmTileW - 1) / kAdmTileW; }
 inline int adm_tiles_y(int band_h) { return (band_h + kAdmTileH - 1) / kAdmTileH; }
 
