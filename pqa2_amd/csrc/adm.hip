@@ -225,7 +225,10 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
   f2 num_h = f2{0.0f, 0.0f}, num_v = num_h, num_d = num_h;
   {
     // band-level mirror of the 3x3 neighbourhood (only bites when the window touches the border)
-    const int lx0 = have ? mirror1(cx - 1, a.ow) - (cx0 - 1) : 0, lx2 = have ? mirror1(cx + 1, a.ow) - (cx0 - 1) : 0;
+    // (clamped into the written part of G: the halo columns themselves look one column further out, carry
+    // weight 0, and must not pull uninitialised LDS -- possibly NaN bits -- into a 0 * x product)
+    const int lx0 = have ? min(max(mirror1(cx - 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
+    const int lx2 = have ? min(max(mirror1(cx + 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
 #pragma unroll
     for (int k = 0; k < NROUND; ++k) {
       const int rp = (tid >> 6) + 4 * k;

@@ -573,6 +573,9 @@ int pqa_submit_device(pqa_ctx* c, int64_t first_index, int32_t n_frames, const p
   if (!c) return PQA_EINVAL;
   if (!ref || !dis || n_frames < 0 || first_index < 0) return fail(c, PQA_EINVAL, "bad argument");
   if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  if (n_frames > c->capacity)
+    return fail(c, PQA_ESTATE, "%d frames in one call exceed result_capacity %d (records would overwrite each other)",
+                n_frames, c->capacity);
   HIPCHK(c, hipSetDevice(c->device));
   int rc = flush_pending(c);
   if (rc != PQA_OK) return rc;

@@ -156,3 +156,28 @@ def test_ragged_clip_lengths_use_the_shorter(tmp_path):
     yuvio.write_y4m(dp, [], info)
     with pytest.raises(ValueError):
         score_files(rp, dp, "vmaf_v0.6.1")
+
+
+def test_analyzer_child_job_drives_torchrun_like_ffmpeg(tmp_path):
+    """The gpus > 1 path of VMAFAnalyzer (a torch.distributed.run child, progress from stderr `frame=` lines),
+    exercised here with one rank because the box has one GPU."""
+    from pqa2_amd import VMAFAnalyzer
+    rp, dp, refs, diss = _pair(tmp_path, 256, 144, 8)
+    a = VMAFAnalyzer()
+    a.set_output_directory(str(tmp_path))
+    a.set_test_name("child")
+    a.gpus = 1
+    ev = {"p": [], "e": []}
+    a.analysis_progress.connect(ev["p"].append)
+    a.error_occurred.connect(ev["e"].append)
+    in_proc = a.analyze_videos(rp, dp, "vmaf_v0.6.1")
+    assert in_proc is not None and ev["e"] == []
+    jp = str(tmp_path / "child_vmaf.json")
+    ok = a._run_child_job(rp, dp, "vmaf_v0.6.1", jp, str(tmp_path / "c_psnr.txt"), str(tmp_path / "c_ssim.txt"), 8)
+    assert ok and ev["e"] == []
+    child = json.load(open(jp))
+    assert [f["metrics"] for f in child["frames"]] == [f["metrics"] for f in in_proc["raw_results"]["frames"]]
+    assert open(tmp_path / "c_psnr.txt").read() == open(in_proc["psnr_log"]).read()
+    # a failing child surfaces as an error signal carrying the return code, like a failing ffmpeg
+    assert not a._run_child_job(rp, str(tmp_path / "nope.y4m"), "vmaf_v0.6.1", jp, None, None, 8)
+    assert "return code" in ev["e"][-1]
