@@ -280,3 +280,47 @@ def test_luma_stats_exact(bpc, w, h):
     from pqa2_amd import bookend
     mean, std, ratio = bookend.brightness_from_stats(got, w * h)
     assert bookend.starts_with_bookend(ratio) and ratio[1] == 1.0 and std[1] == 0.0
+
+
+def test_random_geometry_sweep(oracle64, oracle32):
+    """Seeded sweep over odd / tiny / non-tile-multiple geometries and content types (noise, flat patches,
+    ramps), every feature at once, against the oracle: tile seams, halo mirroring and masked lanes."""
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import sse_from_records
+    rng = np.random.default_rng(20250418)
+    sizes = [(16, 16), (17, 31), (61, 29), (63, 63), (121, 15 + 16), (239, 17), (241, 33), (253, 40), (130, 57),
+             (rng.integers(16, 300), rng.integers(16, 120)), (rng.integers(16, 300), rng.integers(16, 120))]
+    for (w, h) in sizes:
+        w, h = int(w), int(h)
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        kind = rng.integers(0, 3)
+        frames = []
+        for t in range(2):
+            if kind == 0:
+                y = rng.integers(0, 256, (h, w))
+            elif kind == 1:   # flat patches: exact zeros in the high-pass bands, low-variance VIF branch
+                y = np.repeat(np.repeat(rng.integers(0, 256, (-(-h // 16), -(-w // 16))), 16, 0), 16, 1)[:h, :w] + t
+            else:             # ramps
+                y = (np.add.outer(np.arange(h) * 2, np.arange(w)) + 7 * t) % 256
+            frames.append(np.clip(y, 0, 255).astype(np.uint8))
+        refs = [[f, rng.integers(0, 256, (ch, cw), dtype=np.uint8), rng.integers(0, 256, (ch, cw), dtype=np.uint8)] for f in frames]
+        diss = [[np.clip(p.astype(np.int16) + rng.integers(-6, 7, p.shape), 0, 255).astype(np.uint8) for p in fr] for fr in refs]
+        exp = oracle64.clip_features([r[0] for r in refs], [d[0] for d in diss], 8)
+        exp32 = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], 8)
+        with _engine(w, h, n_planes=3, features=N.FEAT_ALL, max_batch=2) as eng:
+            for i in range(2):
+                eng.submit(i, refs[i], diss[i])
+            rec = eng.collect(0, 2)
+        assert np.all(np.isfinite(rec[:, :20])), (w, h, kind)
+        rel = np.abs(rec[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-9)
+        rel32 = np.abs(exp32[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-9)
+        # tiny planes with hard steps amplify f32 cancellation (sigma = E[x^2] - mu^2 on a few pixels): the bar
+        # there is "no worse than a few times libvmaf's own float rounding" (the f32 oracle vs the f64 truth)
+        tol = max(REL_TOL, 4.0 * float(rel32.max()))
+        print(f"\n{w}x{h} kind {int(kind)}: gpu-vs-f64 {rel.max():.2e}, f32-oracle-vs-f64 {rel32.max():.2e}")
+        assert rel.max() < tol, (w, h, int(kind), float(rel.max()), float(rel32.max()), np.unravel_index(rel.argmax(), rel.shape))
+        assert abs(rec[1, 16] - exp[1, 16]) < MOTION_ATOL + 5e-6 * exp[1, 16]
+        sse = sse_from_records(rec)
+        for p in range(3):
+            assert int(sse[1, p]) == oracle32.sse_plane(diss[1][p], refs[1][p], 8)
+            assert abs(rec[1, 17 + p] - oracle32.ssim_plane(diss[1][p], refs[1][p], 8)) < 1e-9
