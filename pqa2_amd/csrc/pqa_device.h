@@ -8,20 +8,10 @@ namespace pqa {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWave = 64;
 constexpr int kBlock = 256;  // 4 waves per workgroup everywhere
 
-// libvmaf border rule (vif_tools.c / adm_tools.c / convolution_internal.h): index -i -> i,
-// index n-1+i -> n-i (high edge repeats the edge sample).  Loop folds planes smaller than a radius.
-__device__ __forceinline__ int mirror(int i, int n) {
-  if (i < 0) i = -i;
-  else if (i >= n) i = 2 * n - i - 1;
-  while (i < 0 || i >= n) {
-    if (i < 0) i = -i;
-    else i = 2 * n - i - 1;
-  }
-  return i;
-}
+// libvmaf border rule (vif_tools.c / adm_tools.c / convolution_internal.h): index -i -> i, index n-1+i -> n-i
+// (the high edge repeats the edge sample).  The oracle keeps the general folding loop; the kernels use mirror1.
 
 // Buffer addressing: a 128-bit resource (base + size, built from wave-uniform values) with the column
 // offset in a VGPR and the row offset in an SGPR.  One plane row costs zero VALU address arithmetic and
@@ -41,7 +31,7 @@ template <> __device__ __forceinline__ float buf_load<float>(rsrc_t r, unsigned 
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off * 4u, row_off * 4u, 0));
 }
 
-// Same rule with a single fold and a clamp.  Exact whenever n > the stencil radius (every plane the
+// The border rule with a single fold and a clamp.  Exact whenever n > the stencil radius (every plane the
 // library accepts: w, h >= 16 at scale 0 and >= 2 at the deepest scale); indices further out belong to
 // tile positions beyond the image whose results are masked, they only need to stay in bounds.
 __device__ __forceinline__ int mirror1(int i, int n) {
@@ -50,27 +40,20 @@ __device__ __forceinline__ int mirror1(int i, int n) {
   return min(max(i, 0), n - 1);
 }
 
-// luma sample -> float as libvmaf picture_copy does: v * inv_scale - 128 (inv_scale = 2^-(bpc-8)).
+// {ref, dis} samples -> float2 as libvmaf picture_copy does: v * inv_scale - 128 (inv_scale = 2^-(bpc-8));
+// f32 planes (pyramid levels) pass through.
 template <typename T> struct PixIO;
 template <> struct PixIO<uint8_t> {
-  static __device__ __forceinline__ float load(const uint8_t* p, float) { return (float)(*p) - 128.0f; }
-  static __device__ __forceinline__ float raw(const uint8_t* p) { return (float)(*p); }
   static __device__ __forceinline__ f2 pair(uint8_t r, uint8_t d, float) {
     return f2{(float)r, (float)d} + f2{-128.0f, -128.0f};
   }
 };
 template <> struct PixIO<uint16_t> {
-  static __device__ __forceinline__ float load(const uint16_t* p, float inv_scale) {
-    return (float)(*p) * inv_scale - 128.0f;
-  }
-  static __device__ __forceinline__ float raw(const uint16_t* p) { return (float)(*p); }
   static __device__ __forceinline__ f2 pair(uint16_t r, uint16_t d, float inv_scale) {
     return f2{(float)r, (float)d} * f2{inv_scale, inv_scale} + f2{-128.0f, -128.0f};
   }
 };
 template <> struct PixIO<float> {
-  static __device__ __forceinline__ float load(const float* p, float) { return *p; }
-  static __device__ __forceinline__ float raw(const float* p) { return *p; }
   static __device__ __forceinline__ f2 pair(float r, float d, float) { return f2{r, d}; }
 };
 
