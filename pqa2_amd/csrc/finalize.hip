@@ -58,8 +58,13 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) 
     if (tid == 0) rec[17 + pl] = s * a.ssim_norm[pl];
   }
   for (int pl = 0; pl < a.n_sse_planes; ++pl) {
-    const unsigned long long* p = a.sse_part[pl] + (int64_t)fr * kSseBlocksPerPlane;
-    unsigned long long v = tid < kSseBlocksPerPlane ? p[tid] : 0ull;
+    unsigned long long v = 0;
+    if (a.sse_use_a[pl]) v += a.sse_part[pl][(int64_t)fr * kSseBlocksPerPlane + tid];
+    if (a.sse_part_b[pl]) v += a.sse_part_b[pl][(int64_t)fr * kSseBlocksPerPlane + tid];
+    if (a.sse_tile_part[pl]) {
+      const unsigned long long* p = a.sse_tile_part[pl] + (int64_t)fr * a.ssim_tiles[pl];
+      for (int i = tid; i < a.ssim_tiles[pl]; i += kBlock) v += p[i];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     __syncthreads();

@@ -62,7 +62,7 @@ hipError_t launch_motion(hipStream_t stream, Elem elem, PlaneRun ref, const void
 
 // ---- PSNR (FFmpeg psnr filter) and SSIM (FFmpeg ssim filter) ----------------------------------
 constexpr int kSseBlocksPerPlane = 256;
-// partials: [n_frames][kSseBlocksPerPlane] uint64 SSE
+// partials: [n_frames][kSseBlocksPerPlane] uint64 SSE of the (w x h) rectangle starting at a.base / b.base
 hipError_t launch_sse(hipStream_t stream, Elem elem, PlaneRun a, PlaneRun b, int n_frames, int w, int h,
                       unsigned long long* partials);
 
@@ -73,8 +73,11 @@ inline int ssim_tiles(int w, int h) {
   return ((ww + kSsimTileBW - 1) / kSsimTileBW) * ((wh + kSsimTileBH - 1) / kSsimTileBH);
 }
 // main = distorted, ref = reference (order of the filter's inputs).  partials: [n_frames][tiles] doubles.
+// sse_partials (nullable): [n_frames][tiles] uint64 -- the squared error of the 4*(w>>2) x 4*(h>>2) part of the
+// plane falls out of the block sums the SSIM needs anyway (ss - 2*s12), so PSNR costs no second pass; the
+// right / bottom remainder strips (w or h not a multiple of 4) are left to launch_sse.
 hipError_t launch_ssim(hipStream_t stream, Elem elem, PlaneRun main, PlaneRun ref, int n_frames, int w, int h,
-                       int max_value, double* partials);
+                       int max_value, double* partials, unsigned long long* sse_partials);
 
 // ---- luma statistics (white bookend-frame detection, the step before the scoring path) ----------
 constexpr int kLumaBlocks = 128;
@@ -90,7 +93,10 @@ struct FinalizeArgs {
   const double* vif_part[4];   int vif_tiles[4];
   const double* adm_part[4];   int adm_tiles[4];   float adm_area[4];  // cropped-window area per scale
   const double* motion_part;   int motion_tiles;   double motion_norm;  // 2^-(bpc-8) / (w*h)
-  const unsigned long long* sse_part[3];
+  const unsigned long long* sse_part[3];      // [n_frames][kSseBlocksPerPlane]: whole plane, or the right strip
+  const unsigned long long* sse_part_b[3];    // nullable: bottom strip
+  const unsigned long long* sse_tile_part[3]; // nullable: [n_frames][ssim_tiles] from the SSIM kernel
+  int sse_use_a[3];                           // 1 when sse_part holds data for this batch
   const double* ssim_part[3];  int ssim_tiles[3];  double ssim_norm[3]; // 1/(windows)
   double* records;             // [capacity][record_stride] ring
   int slot_base, slot_step, capacity;  // record row of batch frame f = (slot_base + f*slot_step) % capacity

@@ -60,6 +60,8 @@ struct pqa_ctx {
   double* motion_part = nullptr;
   int motion_tiles_n = 0;
   unsigned long long* sse_part[3] = {};
+  unsigned long long* sse_part_b[3] = {};
+  unsigned long long* sse_tile_part[3] = {};
   double* ssim_part[3] = {};
   int ssim_tiles_n[3] = {};
   double ssim_norm[3] = {};
@@ -260,13 +262,35 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     HIPCHK(c, launch_motion(st_misc, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h, c->inv_scale, c->motion_part));
   }
   int n_sse = 0, n_ssim = 0;
+  bool sse_a[3] = {false, false, false}, sse_b[3] = {false, false, false}, sse_t[3] = {false, false, false};
+  const bool both = (feat & PQA_FEAT_PSNR) && (feat & PQA_FEAT_SSIM);
   if (feat & PQA_FEAT_PSNR) {
     n_sse = c->n_planes;
     ProfScope ps(c, 12, n, st_misc);
     for (int p = 0; p < c->n_planes; ++p) {
       const PlaneRun a{dis->plane[p], dis->row_pitch[p] / es, dis->frame_pitch[p] / es};
       const PlaneRun b{ref->plane[p], ref->row_pitch[p] / es, ref->frame_pitch[p] / es};
-      HIPCHK(c, launch_sse(st_misc, c->elem, a, b, n, c->pw[p], c->ph[p], c->sse_part[p]));
+      const int pw = c->pw[p], ph = c->ph[p];
+      if (both && c->ssim_tiles_n[p] > 0) {
+        // the SSIM kernel delivers the squared error of the 4-aligned part; only remainder strips are left
+        sse_t[p] = true;
+        const int w4 = (pw >> 2) << 2, h4 = (ph >> 2) << 2;
+        if (w4 < pw) {
+          const PlaneRun ar{(const uint8_t*)a.base + (int64_t)w4 * es, a.row_pitch, a.frame_pitch};
+          const PlaneRun br{(const uint8_t*)b.base + (int64_t)w4 * es, b.row_pitch, b.frame_pitch};
+          HIPCHK(c, launch_sse(st_misc, c->elem, ar, br, n, pw - w4, ph, c->sse_part[p]));
+          sse_a[p] = true;
+        }
+        if (h4 < ph) {
+          const PlaneRun ab{(const uint8_t*)a.base + (int64_t)h4 * a.row_pitch * es, a.row_pitch, a.frame_pitch};
+          const PlaneRun bb{(const uint8_t*)b.base + (int64_t)h4 * b.row_pitch * es, b.row_pitch, b.frame_pitch};
+          HIPCHK(c, launch_sse(st_misc, c->elem, ab, bb, n, w4, ph - h4, c->sse_part_b[p]));
+          sse_b[p] = true;
+        }
+      } else {
+        HIPCHK(c, launch_sse(st_misc, c->elem, a, b, n, pw, ph, c->sse_part[p]));
+        sse_a[p] = true;
+      }
     }
   }
   if (feat & PQA_FEAT_SSIM) {
@@ -275,7 +299,8 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     for (int p = 0; p < c->n_planes; ++p) {
       const PlaneRun a{dis->plane[p], dis->row_pitch[p] / es, dis->frame_pitch[p] / es};
       const PlaneRun b{ref->plane[p], ref->row_pitch[p] / es, ref->frame_pitch[p] / es};
-      HIPCHK(c, launch_ssim(st_misc, c->elem, a, b, n, c->pw[p], c->ph[p], (1 << c->cfg.bit_depth) - 1, c->ssim_part[p]));
+      HIPCHK(c, launch_ssim(st_misc, c->elem, a, b, n, c->pw[p], c->ph[p], (1 << c->cfg.bit_depth) - 1, c->ssim_part[p],
+                            sse_t[p] ? c->sse_tile_part[p] : nullptr));
     }
   }
 
@@ -295,6 +320,9 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   fa.motion_norm = (double)c->inv_scale / ((double)w * h);
   for (int p = 0; p < 3; ++p) {
     fa.sse_part[p] = c->sse_part[p];
+    fa.sse_use_a[p] = sse_a[p] ? 1 : 0;
+    fa.sse_part_b[p] = sse_b[p] ? c->sse_part_b[p] : nullptr;
+    fa.sse_tile_part[p] = sse_t[p] ? c->sse_tile_part[p] : nullptr;
     fa.ssim_part[p] = c->ssim_part[p]; fa.ssim_tiles[p] = c->ssim_tiles_n[p]; fa.ssim_norm[p] = c->ssim_norm[p];
   }
   fa.records = c->records;
@@ -516,12 +544,16 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     CREATE_TRY(dev_alloc(c, &c->last_luma, (size_t)c->last_luma_pitch * h));
   }
   for (int p = 0; p < c->n_planes; ++p) {
-    if (cfg->features & PQA_FEAT_PSNR) CREATE_TRY(dev_alloc(c, &c->sse_part[p], (size_t)kSseBlocksPerPlane * B));
+    if (cfg->features & PQA_FEAT_PSNR) {
+      CREATE_TRY(dev_alloc(c, &c->sse_part[p], (size_t)kSseBlocksPerPlane * B));
+      CREATE_TRY(dev_alloc(c, &c->sse_part_b[p], (size_t)kSseBlocksPerPlane * B));
+    }
     if (cfg->features & PQA_FEAT_SSIM) {
       c->ssim_tiles_n[p] = ssim_tiles(c->pw[p], c->ph[p]);
       const int ww = (c->pw[p] >> 2) - 1, wh = (c->ph[p] >> 2) - 1;
       c->ssim_norm[p] = (ww > 0 && wh > 0) ? 1.0 / ((double)ww * wh) : 0.0;
       CREATE_TRY(dev_alloc(c, &c->ssim_part[p], (size_t)(c->ssim_tiles_n[p] ? c->ssim_tiles_n[p] : 1) * B));
+      CREATE_TRY(dev_alloc(c, &c->sse_tile_part[p], (size_t)(c->ssim_tiles_n[p] ? c->ssim_tiles_n[p] : 1) * B));
     }
   }
   CREATE_TRY(dev_alloc(c, &c->luma_part, (size_t)kLumaBlocks * 3 * B));

@@ -82,6 +82,7 @@ struct SsimArgs {
   int tiles_x, n_tiles;
   int max_value;
   double* partials;
+  unsigned long long* sse_partials;  // nullable: per-tile SSE of the blocks this tile owns (ss - 2*s12, exact)
 };
 
 constexpr int SBW = kSsimTileBW + 1, SBH = kSsimTileBH + 1;  // block sums needed per tile
@@ -90,6 +91,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void ssim_kernel(const SsimArgs a) {
   __shared__ unsigned sums[4][SBH][SBW + 1];
   __shared__ double red[4];
+  __shared__ unsigned long long redu[4];
   const int tile = xcd_remap(blockIdx.x, a.n_tiles);
   const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
   const int fr = blockIdx.y;
@@ -100,6 +102,10 @@ __global__ __launch_bounds__(kBlock) void ssim_kernel(const SsimArgs a) {
   const bool aligned4 = sizeof(T) == 1 && (a.row_pitch_m % 4 == 0) && (a.row_pitch_r % 4 == 0) &&
                         ((uintptr_t)pm % 4 == 0) && ((uintptr_t)pr % 4 == 0);
 
+  // A tile needs one block row / column more than it has windows; for the squared error each 4x4 block is
+  // owned by exactly one tile (the extra row / column belongs to the neighbour, except at the plane's end).
+  const bool last_x = tx == a.tiles_x - 1, last_y = (tile / a.tiles_x) == (a.n_tiles / a.tiles_x) - 1;
+  unsigned long long sse = 0;
   for (int item = tid; item < SBW * SBH; item += kBlock) {
     const int ly = item / SBW, lx = item - ly * SBW;
     const int bx = bx0 + lx, by = by0 + ly;
@@ -133,8 +139,17 @@ __global__ __launch_bounds__(kBlock) void ssim_kernel(const SsimArgs a) {
       }
     }
     sums[0][ly][lx] = s1; sums[1][ly][lx] = s2; sums[2][ly][lx] = ss; sums[3][ly][lx] = s12;
+    if ((lx < kSsimTileBW || last_x) && (ly < kSsimTileBH || last_y))
+      sse += (unsigned long long)ss - 2ull * s12;  // sum (a-b)^2 over the block; zero for blocks outside the plane
+  }
+  if (a.sse_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sse += __shfl_down(sse, off, 64);
+    if ((tid & 63) == 0) redu[tid >> 6] = sse;
   }
   __syncthreads();
+  if (a.sse_partials && tid == 0)
+    a.sse_partials[(int64_t)fr * a.n_tiles + tile] = (redu[0] + redu[1]) + (redu[2] + redu[3]);
 
   // one 8x8 window (2x2 blocks) per thread
   const int wx = tid & 31, wy = tid >> 5;
@@ -179,7 +194,7 @@ hipError_t launch_sse(hipStream_t stream, Elem elem, PlaneRun pa, PlaneRun pb, i
 }
 
 hipError_t launch_ssim(hipStream_t stream, Elem elem, PlaneRun pm, PlaneRun pr, int n_frames, int w, int h,
-                       int max_value, double* partials) {
+                       int max_value, double* partials, unsigned long long* sse_partials) {
   if (n_frames <= 0) return hipSuccess;
   SsimArgs a{};
   a.main = pm.base; a.ref = pr.base;
@@ -191,6 +206,7 @@ hipError_t launch_ssim(hipStream_t stream, Elem elem, PlaneRun pm, PlaneRun pr, 
   a.tiles_x = ((a.bw - 1) + kSsimTileBW - 1) / kSsimTileBW;
   a.max_value = max_value;
   a.partials = partials;
+  a.sse_partials = sse_partials;
   const dim3 grid(a.n_tiles, n_frames), block(kBlock);
   switch (elem) {
     case ELEM_U8: hipLaunchKernelGGL((ssim_kernel<uint8_t>), grid, block, 0, stream, a); break;
