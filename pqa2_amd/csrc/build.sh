@@ -12,5 +12,5 @@ for f in vif adm motion psnr_ssim luma_stats finalize pqa_api; do
   OBJS+=("$f.o")
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libpqa_vmaf.so "${OBJS[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o libpqa_vmaf.so "${OBJS[@]}"
 echo "built $(pwd)/libpqa_vmaf.so"
