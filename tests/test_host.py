@@ -209,3 +209,24 @@ def test_bookend_rules_on_exact_stats():
         m2, s2, r2 = bookend.brightness_from_stats(st2, 2000)
         assert bookend.is_white_refined(m2, s2, r2, t, 30).tolist() == [bool(ref_refined(f, t, 30)) for f in frames]
     assert bookend.starts_with_bookend(ratio) and not bookend.starts_with_bookend(ratio[1:2])
+
+
+def test_bootstrap_collection_and_pooling_keys():
+    """vmaf_b_v0.6.3: 21 nu-SVR models; entry 0 scores `vmaf`, entries 1..20 give the bagging statistics."""
+    m = M.load_model("vmaf_b_v0.6.3")
+    rng = np.random.default_rng(2)
+    n = 6
+    rec = np.zeros((n, 24))
+    rec[:, 0:4] = rng.uniform(0.5, 1.0, (n, 4)); rec[:, 4:8] = 1.0
+    rec[:, 8:12] = rng.uniform(0.8, 1.0, (n, 4)); rec[:, 12:16] = 1.0
+    rec[:, 16] = rng.uniform(0, 8, n); rec[0, 16] = 0
+    out = M.score_frames(m, M.metrics_from_records(rec, 1920, 1080, "integer_"))
+    for k in ("vmaf", "vmaf_bagging", "vmaf_stddev", "vmaf_ci_p95_lo", "vmaf_ci_p95_hi"):
+        assert k in out and out[k].shape == (n,)
+    assert np.all(out["vmaf_ci_p95_lo"] <= out["vmaf_bagging"]) and np.all(out["vmaf_bagging"] <= out["vmaf_ci_p95_hi"])
+    assert np.all(out["vmaf_stddev"] > 0) and np.all(np.abs(out["vmaf"] - out["vmaf_bagging"]) < 5.0)
+    single = M.load_model("vmaf_b_v0.6.3").models[0].predict(
+        np.column_stack([out["integer_adm2"], out["integer_motion2"]] + [out[f"integer_vif_scale{s}"] for s in range(4)]))
+    np.testing.assert_array_equal(single, out["vmaf"])
+    log = report.build_vmaf_log(out, 30.0)
+    assert set(log["pooled_metrics"]["vmaf_bagging"]) == {"min", "max", "mean", "harmonic_mean"}
