@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="2160p", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=300, help="frames per rank")
-    ap.add_argument("--batch", type=int, default=32, help="frames per kernel launch")
+    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (0: the library's auto size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=0, help="0: sized for ~12 s of CPU work")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(16, host cores) -- the 1-GPU share of the box")
@@ -83,6 +83,8 @@ def main():
             dist.init_process_group("gloo")
 
     w, h, bpc, model_name, side = WORKLOADS[args.workload]
+    if args.batch <= 0:   # same rule as pqa_create: about 512 MiB of luma per launch, 8..256 frames
+        args.batch = int(max(8, min(256, (512 << 20) // (2 * w * h * (1 if bpc <= 8 else 2)))))
     F = args.frames
     total = F * world
     a = rank * F
