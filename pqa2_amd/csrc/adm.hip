@@ -125,6 +125,7 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
   const float cos_1deg_sq = 0.99969541350954788f;  // cos(pi/180)^2
   const float eps = 1e-30f;
   const int lcx = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // row pairs are per wave: row tests stay scalar
   const bool have = lcx < GW;
   const int lcxs = have ? lcx : 0;
   const int cx = cx0 - 1 + lcxs;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
   f2 den_h = f2{0.0f, 0.0f}, den_v = den_h, den_d = den_h;
 #pragma unroll
   for (int k = 0; k < NROUND; ++k) {
-    const int rp = (tid >> 6) + 4 * k;
+    const int rp = wave + 4 * k;
     const int lcyA = 2 * rp, cyA = cy0 - 1 + lcyA, cyB = cyA + 1;
     f2 s[4][4];
 #pragma unroll
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
     const int lx2 = have ? min(max(mirror1(cx + 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
 #pragma unroll
     for (int k = 0; k < NROUND; ++k) {
-      const int rp = (tid >> 6) + 4 * k;
+      const int rp = wave + 4 * k;
       const int lcyA = 2 * rp, cyA = cy0 - 1 + lcyA;
       // rows A-1, A, B, B+1 of the masking signal, clamped into the tile's halo'd grid (the clamped ones
       // belong to elements that are not inner and carry weight 0)
