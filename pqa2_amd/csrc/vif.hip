@@ -242,12 +242,15 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
     // validity as 0/1 weights folded into the accumulation (an fma instead of an add): no branches, and
     // out-of-image positions of edge tiles still hold finite values (mirrored real pixels)
     const int gyA = y0 + 2 * rp;
-    const float mrow[2] = {gyA < a.h ? 1.0f : 0.0f, gyA + 1 < a.h ? 1.0f : 0.0f};
+    const bool vrow[2] = {gyA < a.h, gyA + 1 < a.h};
     f2 num2 = f2{0.0f, 0.0f}, den2 = f2{0.0f, 0.0f};
-    const f2 mrow2 = f2{mrow[0], mrow[1]};
+    // the log terms of the sigma1_sq >= sigma_nsq branch are summed as the log of a product: per row of
+    // the pair the four columns' arguments (each in [2, 2^15]) are multiplied first, so the thread takes
+    // 6 v_log_f32 instead of 16 and needs no reciprocal for num's ratio (log a/b = log a - log b)
+    f2 pn = f2{1.0f, 1.0f}, qn = f2{1.0f, 1.0f}, pd = f2{1.0f, 1.0f};
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      const float mcol = (x0 + seg * 4 + o) < a.w ? 1.0f : 0.0f;
+      const bool vcol = (x0 + seg * 4 + o) < a.w;
       // the two rows of the pair go through the statistic together: every add / mul / fma is packed,
       // only max / min / select / rcp / log are per element
       const f2 mu1 = out[0][o], mu2 = out[1][o];
@@ -272,20 +275,25 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
       // bound makes g*g = 0 when sigma12 < 0, i.e. num_val = log2(1) = 0 -- libvmaf's `if (sigma12 < 0) num_val = 0`
       g = f2{__builtin_amdgcn_fmed3f(g.x, 0.0f, a.gain_limit), __builtin_amdgcn_fmed3f(g.y, 0.0f, a.gain_limit)};
       const f2 svn = sv + f2{sigma_nsq, sigma_nsq};
-      const f2 narg = __builtin_elementwise_fma(g * g * s1, f2{fast_rcp(svn.x), fast_rcp(svn.y)}, f2{1.0f, 1.0f});
+      // num_val = log2(1 + g^2 sigma1_sq / (sv_sq + sigma_nsq)) = log2(narg) - log2(svn)
+      const f2 narg = __builtin_elementwise_fma(g * g, s1, svn);
       const f2 darg = __builtin_elementwise_fma(s1, f2{1.0f / sigma_nsq, 1.0f / sigma_nsq}, f2{1.0f, 1.0f});
-      f2 nv = f2{fast_log2(narg.x), fast_log2(narg.y)};
-      f2 dv = f2{fast_log2(darg.x), fast_log2(darg.y)};
       const f2 low = __builtin_elementwise_fma(s2, f2{-sigma_max_inv, -sigma_max_inv}, f2{1.0f, 1.0f});
-      if (s1.x < sigma_nsq) { nv.x = low.x; dv.x = 1.0f; }
-      if (s1.y < sigma_nsq) { nv.y = low.y; dv.y = 1.0f; }
-      const f2 m = mrow2 * f2{mcol, mcol};
-      num2 = __builtin_elementwise_fma(m, nv, num2);
-      den2 = __builtin_elementwise_fma(m, dv, den2);
+      // validity and the branch choice as selects: out-of-image positions of edge tiles hold finite values
+      // (mirrored real pixels), they contribute a factor 1 and a weight 0
+      const bool vx = vcol && vrow[0], vy = vcol && vrow[1];
+      const bool hx = vx && !(s1.x < sigma_nsq), hy = vy && !(s1.y < sigma_nsq);
+      const bool lx = vx && (s1.x < sigma_nsq), ly = vy && (s1.y < sigma_nsq);
+      pn *= f2{hx ? narg.x : 1.0f, hy ? narg.y : 1.0f};
+      qn *= f2{hx ? svn.x : 1.0f, hy ? svn.y : 1.0f};
+      pd *= f2{hx ? darg.x : 1.0f, hy ? darg.y : 1.0f};
+      const f2 wl = f2{lx ? 1.0f : 0.0f, ly ? 1.0f : 0.0f};
+      num2 = __builtin_elementwise_fma(wl, low, num2);
+      den2 += wl;
       __builtin_amdgcn_sched_barrier(0);  // two pixels' worth of temporaries live at a time
     }
-    num = num2.x + num2.y;
-    den = den2.x + den2.y;
+    num = (num2.x + num2.y) + ((fast_log2(pn.x) - fast_log2(qn.x)) + (fast_log2(pn.y) - fast_log2(qn.y)));
+    den = (den2.x + den2.y) + (fast_log2(pd.x) + fast_log2(pd.y));
   }
   const float part[2] = {num, den};
   double v[2];
