@@ -107,7 +107,7 @@ def main():
     eng = FeatureEngine(w, h, bit_depth=bpc, n_planes=n_planes, features=feats, device=local_rank,
                         max_batch=args.batch, result_capacity=max(F, 1024),
                         vif_enhn_gain_limit=model.vif_enhn_gain_limit,
-                        adm_enhn_gain_limit=model.adm_enhn_gain_limit)
+                        adm_enhn_gain_limit=model.adm_enhn_gain_limit, vif_border=model.vif_border)
     prefix = "integer_" if model.is_integer else ""
     result = {}
 
@@ -221,7 +221,7 @@ def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads, gpu_records,
         diss = [d.view(np.uint16) for d in diss]
     t0 = time.perf_counter()
     exp = orc.clip_features_mt(refs, diss, bpc, threads, vif_gain_limit=model.vif_enhn_gain_limit,
-                               adm_gain_limit=model.adm_enhn_gain_limit)
+                               adm_gain_limit=model.adm_enhn_gain_limit, vif_border101=bool(model.vif_border))
     dt = time.perf_counter() - t0
     got = gpu_records[:n_sample, :17]
     rel = np.abs(got[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-12)

@@ -83,7 +83,19 @@ typedef struct pqa_config {
                                   motion on every frame (0/1 -> every frame)                      */
   double vif_enhn_gain_limit;  /* 100.0 default; 1.0 for *neg models (feature_opts_dicts)         */
   double adm_enhn_gain_limit;  /* 100.0 default; 1.0 for *neg models                              */
+  uint32_t vif_border;         /* PQA_VIF_BORDER_*: which libvmaf extractor's VIF padding to follow  */
+  uint32_t reserved0;          /* must be 0                                                       */
 } pqa_config;
+
+/* libvmaf has two VIF extractors with different image-border handling.  `model=version=vmaf_v0.6.1`
+ * (app/vmaf_analyzer.py:377) names VMAF_integer_feature_vif_* (models/vmaf_v0.6.1.json:31-38), i.e.
+ * integer_vif.c, which pads by reflect-101 on all four edges; the vmaf_float_* models name float_vif
+ * (vif_tools.c), which repeats the edge sample at the bottom/right edge.  The arithmetic here is f32 in
+ * both cases (DESIGN.md "float vs fixed-point" quantifies the residual); this selects the border only. */
+enum {
+  PQA_VIF_BORDER_FLOAT = 0,   /* vif_tools.c:   index -i -> i,  n-1+i -> n-i    */
+  PQA_VIF_BORDER_INTEGER = 1  /* integer_vif.c: index -i -> i,  n-1+i -> n-1-i  */
+};
 
 /* A clip already resident in device memory (HBM): frame f of plane p starts at
  * plane[p] + f * frame_pitch[p]; rows are row_pitch[p] bytes apart.  Pitches are in BYTES. */

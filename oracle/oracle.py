@@ -42,9 +42,9 @@ class Oracle:
         L = self.lib
         L.orc_real_size.restype = C.c_int
         assert L.orc_real_size() == np.dtype(self.real).itemsize
-        L.orc_frame_features.restype = C.c_int
-        L.orc_frame_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_frame_features2.restype = C.c_int
+        L.orc_frame_features2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_sse_plane.restype = C.c_uint64
         L.orc_sse_plane.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_ssim_plane.restype = C.c_double
@@ -79,8 +79,9 @@ class Oracle:
     # -- per-frame features ---------------------------------------------------------------
     def frame_features(self, ref_y: np.ndarray, dis_y: np.ndarray, bpc: int = 8,
                        prev_blur: np.ndarray | None = None,
-                       vif_gain_limit: float = 100.0, adm_gain_limit: float = 100.0):
-        """Returns (feat[17] float64, blur plane) for one frame pair (luma planes, uint8/uint16)."""
+                       vif_gain_limit: float = 100.0, adm_gain_limit: float = 100.0, vif_border101: bool = False):
+        """Returns (feat[17] float64, blur plane) for one frame pair (luma planes, uint8/uint16).
+        vif_border101: pad VIF the way integer_vif.c does (reflect-101 on both edges) instead of vif_tools.c."""
         ref_y = np.ascontiguousarray(ref_y)
         dis_y = np.ascontiguousarray(dis_y)
         assert ref_y.shape == dis_y.shape and ref_y.dtype == dis_y.dtype
@@ -88,29 +89,31 @@ class Oracle:
         h, w = ref_y.shape
         feat = np.zeros(N_FEAT, np.float64)
         blur = np.empty((h, w), self.real)
-        rc = self.lib.orc_frame_features(
+        rc = self.lib.orc_frame_features2(
             ref_y.ctypes.data, dis_y.ctypes.data, ref_y.strides[0], bpc, w, h,
             vif_gain_limit, adm_gain_limit,
             prev_blur.ctypes.data if prev_blur is not None else None,
-            blur.ctypes.data, feat.ctypes.data)
+            blur.ctypes.data, feat.ctypes.data, 1 if vif_border101 else 0)
         if rc != 0:
             raise MemoryError("oracle allocation failed")
         return feat, blur
 
     def clip_features(self, ref_frames, dis_frames, bpc: int = 8, prev_ref: np.ndarray | None = None,
-                      vif_gain_limit: float = 100.0, adm_gain_limit: float = 100.0) -> np.ndarray:
+                      vif_gain_limit: float = 100.0, adm_gain_limit: float = 100.0,
+                      vif_border101: bool = False) -> np.ndarray:
         """[n, 17] raw feature records for a clip; motion of frame 0 uses prev_ref (halo) if given."""
         prev_blur = None
         if prev_ref is not None:
             _, prev_blur = self._blur_only(prev_ref, bpc)
         out = []
         for r, d in zip(ref_frames, dis_frames):
-            f, prev_blur = self.frame_features(r, d, bpc, prev_blur, vif_gain_limit, adm_gain_limit)
+            f, prev_blur = self.frame_features(r, d, bpc, prev_blur, vif_gain_limit, adm_gain_limit, vif_border101)
             out.append(f)
         return np.stack(out) if out else np.zeros((0, N_FEAT))
 
     def clip_features_mt(self, ref_frames, dis_frames, bpc: int = 8, threads: int = 4,
-                         vif_gain_limit: float = 100.0, adm_gain_limit: float = 100.0) -> np.ndarray:
+                         vif_gain_limit: float = 100.0, adm_gain_limit: float = 100.0,
+                         vif_border101: bool = False) -> np.ndarray:
         """clip_features on a thread pool (ctypes releases the GIL): frame i is independent once it blurs
         reference frame i-1 itself.  Same numbers as clip_features."""
         from concurrent.futures import ThreadPoolExecutor
@@ -118,7 +121,8 @@ class Oracle:
 
         def one(i):
             prev_blur = self._blur_only(ref_frames[i - 1], bpc)[1] if i > 0 else None
-            return self.frame_features(ref_frames[i], dis_frames[i], bpc, prev_blur, vif_gain_limit, adm_gain_limit)[0]
+            return self.frame_features(ref_frames[i], dis_frames[i], bpc, prev_blur, vif_gain_limit, adm_gain_limit,
+                                       vif_border101)[0]
 
         with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
             out = list(ex.map(one, range(n)))

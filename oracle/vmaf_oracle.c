@@ -103,15 +103,26 @@ enum { VIF_PLAIN = 0, VIF_SQ = 1, VIF_XY = 2 };
 
 /* separable filter, vertical pass first (per output row), then horizontal -- vif_filter1d_s.
  * mode SQ squares the sample in the vertical pass, XY multiplies the two sources there. */
+/* integer_vif.c pads differently from vif_tools.c: reflect-101 on BOTH edges (pad_top_and_bottom,
+ * PADDING_SQ_DATA: index n-1+i -> n-1-i).  border101 selects that rule so the float arithmetic can be
+ * compared with the fixed-point extractor the default models name (see vmaf_int_oracle.c). */
+static inline int mirror_vif(int i, int n, int border101)
+{
+    if (!border101) return mirror(i, n);
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
 static void vif_filter1d(const real *f, int fw, const real *a, const real *b, int mode,
-                         real *dst, int w, int h)
+                         real *dst, int w, int h, int border101)
 {
     real *tmp = (real *)malloc(sizeof(real) * (size_t)w);
     for (int i = 0; i < h; ++i) {
         for (int j = 0; j < w; ++j) {
             real accum = 0;
             for (int fi = 0; fi < fw; ++fi) {
-                int ii = mirror(i - fw / 2 + fi, h);
+                int ii = mirror_vif(i - fw / 2 + fi, h, border101);
                 real v = a[(size_t)ii * w + j];
                 real img = mode == VIF_PLAIN ? v : (mode == VIF_SQ ? v * v : v * b[(size_t)ii * w + j]);
                 accum += f[fi] * img;
@@ -121,7 +132,7 @@ static void vif_filter1d(const real *f, int fw, const real *a, const real *b, in
         for (int j = 0; j < w; ++j) {
             real accum = 0;
             for (int fj = 0; fj < fw; ++fj) {
-                int jj = mirror(j - fw / 2 + fj, w);
+                int jj = mirror_vif(j - fw / 2 + fj, w, border101);
                 accum += f[fj] * tmp[jj];
             }
             dst[(size_t)i * w + j] = accum;
@@ -180,8 +191,8 @@ static void vif_statistic(const real *mu1, const real *mu2, const real *xx, cons
 }
 
 /* out[0..3] = num per scale, out[4..7] = den per scale.  ref/dis are picture_copy'd planes. */
-ORC_EXPORT int orc_vif(const real *ref, const real *dis, int w, int h, double vif_enhn_gain_limit,
-                       double *out)
+ORC_EXPORT int orc_vif2(const real *ref, const real *dis, int w, int h, double vif_enhn_gain_limit,
+                        int border101, double *out)
 {
     size_t n = (size_t)w * h;
     real *buf = (real *)malloc(sizeof(real) * n * 9);
@@ -197,23 +208,29 @@ ORC_EXPORT int orc_vif(const real *ref, const real *dis, int w, int h, double vi
         int fw = fwidth[scale];
         if (scale > 0) {
             /* filter the previous scale with THIS scale's kernel, keep even samples */
-            vif_filter1d(f, fw, cur_ref, NULL, VIF_PLAIN, mu1, w, h);
-            vif_filter1d(f, fw, cur_dis, NULL, VIF_PLAIN, mu2, w, h);
+            vif_filter1d(f, fw, cur_ref, NULL, VIF_PLAIN, mu1, w, h, border101);
+            vif_filter1d(f, fw, cur_dis, NULL, VIF_PLAIN, mu2, w, h, border101);
             vif_dec2(mu1, ref_s, w, h);
             vif_dec2(mu2, dis_s, w, h);
             w /= 2; h /= 2;
             memcpy(cur_ref, ref_s, sizeof(real) * (size_t)w * h);
             memcpy(cur_dis, dis_s, sizeof(real) * (size_t)w * h);
         }
-        vif_filter1d(f, fw, cur_ref, NULL, VIF_PLAIN, mu1, w, h);
-        vif_filter1d(f, fw, cur_dis, NULL, VIF_PLAIN, mu2, w, h);
-        vif_filter1d(f, fw, cur_ref, NULL, VIF_SQ, xx, w, h);
-        vif_filter1d(f, fw, cur_dis, NULL, VIF_SQ, yy, w, h);
-        vif_filter1d(f, fw, cur_ref, cur_dis, VIF_XY, xy, w, h);
+        vif_filter1d(f, fw, cur_ref, NULL, VIF_PLAIN, mu1, w, h, border101);
+        vif_filter1d(f, fw, cur_dis, NULL, VIF_PLAIN, mu2, w, h, border101);
+        vif_filter1d(f, fw, cur_ref, NULL, VIF_SQ, xx, w, h, border101);
+        vif_filter1d(f, fw, cur_dis, NULL, VIF_SQ, yy, w, h, border101);
+        vif_filter1d(f, fw, cur_ref, cur_dis, VIF_XY, xy, w, h, border101);
         vif_statistic(mu1, mu2, xx, yy, xy, w, h, vif_enhn_gain_limit, &out[scale], &out[4 + scale]);
     }
     free(buf);
     return 0;
+}
+
+ORC_EXPORT int orc_vif(const real *ref, const real *dis, int w, int h, double vif_enhn_gain_limit,
+                       double *out)
+{
+    return orc_vif2(ref, dis, w, h, vif_enhn_gain_limit, 0, out);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -560,9 +577,9 @@ ORC_EXPORT double orc_ssim_plane(const void *a, int a_stride, const void *b, int
  *   feat[16]    motion (SAD mean vs prev_blur, 0 when prev_blur == NULL)
  * blur_out (w*h reals) receives this frame's blurred reference for the next call.
  * ---------------------------------------------------------------------------------------- */
-ORC_EXPORT int orc_frame_features(const void *ref_luma, const void *dis_luma, int stride_bytes, int bpc,
-                                  int w, int h, double vif_gain_limit, double adm_gain_limit,
-                                  const real *prev_blur, real *blur_out, double *feat)
+ORC_EXPORT int orc_frame_features2(const void *ref_luma, const void *dis_luma, int stride_bytes, int bpc,
+                                   int w, int h, double vif_gain_limit, double adm_gain_limit,
+                                   const real *prev_blur, real *blur_out, double *feat, int vif_border101)
 {
     size_t n = (size_t)w * h;
     real *ref = (real *)malloc(sizeof(real) * n);
@@ -570,12 +587,20 @@ ORC_EXPORT int orc_frame_features(const void *ref_luma, const void *dis_luma, in
     if (!ref || !dis) return -1;
     orc_picture_copy(ref_luma, stride_bytes, bpc, w, h, ref);
     orc_picture_copy(dis_luma, stride_bytes, bpc, w, h, dis);
-    int rc = orc_vif(ref, dis, w, h, vif_gain_limit, feat);
+    int rc = orc_vif2(ref, dis, w, h, vif_gain_limit, vif_border101, feat);
     if (!rc) rc = orc_adm(ref, dis, w, h, adm_gain_limit, feat + 8);
     orc_motion_blur(ref, w, h, blur_out);
     feat[16] = prev_blur ? orc_motion_sad(prev_blur, blur_out, w, h) : 0.0;
     free(ref); free(dis);
     return rc;
+}
+
+ORC_EXPORT int orc_frame_features(const void *ref_luma, const void *dis_luma, int stride_bytes, int bpc,
+                                  int w, int h, double vif_gain_limit, double adm_gain_limit,
+                                  const real *prev_blur, real *blur_out, double *feat)
+{
+    return orc_frame_features2(ref_luma, dis_luma, stride_bytes, bpc, w, h, vif_gain_limit, adm_gain_limit,
+                               prev_blur, blur_out, feat, 0);
 }
 
 ORC_EXPORT int orc_real_size(void) { return (int)sizeof(real); }

@@ -31,10 +31,11 @@ inline int vif_tiles_x(int scale, int w) { return (w + vif_tile_w(scale) - 1) / 
 inline int vif_tiles_y(int h) { return (h + kVifTileH - 1) / kVifTileH; }
 
 // partials: [n_frames][tiles][2] doubles (num, den), tiles = tiles_x * tiles_y.
+// border101: 0 = vif_tools.c border rule (high edge repeated), 1 = integer_vif.c padding (reflect-101).
 // For scale < 3 the same launch also produces the next scale's input (fused decimation): the planes are
 // filtered with the next scale's kernel and even samples kept -> next_ref / next_dis, (w/2 x h/2) f32.
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
-                           int w, int h, float inv_scale, float gain_limit, double* partials,
+                           int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
                            MutPlaneRun next_ref, MutPlaneRun next_dis);
 
 // ---- ADM ------------------------------------------------------------------------------------

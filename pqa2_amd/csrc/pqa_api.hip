@@ -215,7 +215,8 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       {
         ProfScope ps(c, s, sp_n, st);
         HIPCHK(c, launch_vif_stat(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
-                                  (float)c->cfg.vif_enhn_gain_limit, c->vif_part[s], nr, nd));
+                                  (float)c->cfg.vif_enhn_gain_limit, c->cfg.vif_border == PQA_VIF_BORDER_INTEGER,
+                                  c->vif_part[s], nr, nd));
       }
       if (s < 3) {
         Level& L = c->vif_lv[s + 1];
@@ -453,6 +454,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   if (cfg->chroma_hshift > 2 || cfg->chroma_vshift > 2) return fail(nullptr, PQA_EINVAL, "bad chroma shift");
   if ((cfg->features & ~(uint32_t)PQA_FEAT_ALL) || cfg->features == 0)
     return fail(nullptr, PQA_EINVAL, "bad feature mask 0x%x", cfg->features);
+  if (cfg->vif_border > PQA_VIF_BORDER_INTEGER || cfg->reserved0 != 0)
+    return fail(nullptr, PQA_EINVAL, "bad vif_border %u", cfg->vif_border);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, PQA_EDEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -675,11 +678,17 @@ int pqa_submit(pqa_ctx* c, int64_t frame_index, const void* const ref_planes[3],
       copy_plane_rows(slot + c->plane_off[side][p], c->slot_row_pitch[p], (const uint8_t*)planes[p], strides[p],
                       (size_t)c->pw[p] * c->esize, c->ph[p]);
   };
-  if (c->slot_bytes >= (4u << 20)) {
-    std::thread helper(pack, 0, ref_planes, ref_strides);
-    pack(1, dis_planes, dis_strides);
-    helper.join();
-  } else {
+  bool split = c->slot_bytes >= (4u << 20);
+  if (split) {
+    try {  // no exception may cross the C ABI: if the helper cannot start, pack serially
+      std::thread helper(pack, 0, ref_planes, ref_strides);
+      pack(1, dis_planes, dis_strides);
+      helper.join();
+    } catch (...) {
+      split = false;
+    }
+  }
+  if (!split) {
     pack(0, ref_planes, ref_strides);
     pack(1, dis_planes, dis_strides);
   }

@@ -39,6 +39,13 @@ __device__ __forceinline__ int mirror1(int i, int n) {
   i = i >= n ? 2 * n - i - 1 : i;
   return min(max(i, 0), n - 1);
 }
+// Same with the high-edge fold point as a parameter: fold = 2n - 1 is mirror1 (vif_tools.c), fold = 2n - 2
+// is reflect-101 on both edges, the padding integer_vif.c applies (pad_top_and_bottom / PADDING_SQ_DATA).
+__device__ __forceinline__ int mirror_fold(int i, int n, int fold) {
+  i = i < 0 ? -i : i;
+  i = i >= n ? fold - i : i;
+  return min(max(i, 0), n - 1);
+}
 
 // {ref, dis} samples -> float2 as libvmaf picture_copy does: v * inv_scale - 128 (inv_scale = 2^-(bpc-8));
 // f32 planes (pyramid levels) pass through.

@@ -66,6 +66,7 @@ struct VifStatArgs {
   const void* dis;
   int64_t row_pitch_r, frame_pitch_r, row_pitch_d, frame_pitch_d;
   int w, h, tiles_x, n_tiles;
+  int fold_w, fold_h;  // high-edge fold points of the border rule (pqa_device.h mirror_fold)
   float inv_scale, gain_limit;
   double* partials;
   // fused decimation (scale s -> s+1): filtered with the NEXT scale's taps, even samples kept
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
     const int col = tid;   // one column per thread; the 8-row strip is the whole tile: rows are uniform
     constexpr int seg = 0;
     if (col < COLS) {
-      const unsigned gx = (unsigned)mirror1(x0 - R + col, a.w);
+      const unsigned gx = (unsigned)mirror_fold(x0 - R + col, a.w, a.fold_w);
       const unsigned pitch_r = (unsigned)a.row_pitch_r, pitch_d = (unsigned)a.row_pitch_d;  // planes < 4 G samples
       const auto rsrc_r = make_rsrc(ref, (unsigned)a.h * pitch_r * (unsigned)sizeof(T));
       const auto rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d * (unsigned)sizeof(T));
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
         for (int i = 0; i < G; ++i) {
           const int j = g * G + i;
           if (j < NIN) {
-            const unsigned gy = (unsigned)mirror1(y0 + seg * S - R + j, a.h);
+            const unsigned gy = (unsigned)mirror_fold(y0 + seg * S - R + j, a.h, a.fold_h);
             // scalar frame base + 32-bit (row * pitch + column) lane offset -> global_load with an SGPR base
             // buffer_load: lane offset (column) in a VGPR, row offset in an SGPR -> no per-load VALU
             rn[i] = buf_load<T>(rsrc_r, gx, gy * pitch_r);
@@ -324,7 +325,7 @@ constexpr int kVifTW[4] = {240, 248, 252, 252};
 int vif_tile_w(int scale) { return kVifTW[scale]; }
 
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
-                           int w, int h, float inv_scale, float gain_limit, double* partials,
+                           int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
                            MutPlaneRun next_ref, MutPlaneRun next_dis) {
   if (n_frames <= 0) return hipSuccess;
   VifStatArgs a{};
@@ -332,6 +333,7 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
   a.row_pitch_r = ref.row_pitch; a.frame_pitch_r = ref.frame_pitch;
   a.row_pitch_d = dis.row_pitch; a.frame_pitch_d = dis.frame_pitch;
   a.w = w; a.h = h;
+  a.fold_w = 2 * w - (border101 ? 2 : 1); a.fold_h = 2 * h - (border101 ? 2 : 1);
   a.tiles_x = vif_tiles_x(scale, w);
   a.n_tiles = a.tiles_x * vif_tiles_y(h);
   a.inv_scale = inv_scale; a.gain_limit = gain_limit;

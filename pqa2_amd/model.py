@@ -91,6 +91,12 @@ class VmafModel:
         return any("integer" in n for n in self.main.feature_names)
 
     @property
+    def vif_border(self) -> int:
+        """pqa_config.vif_border for this model: VMAF_integer_feature_vif_* names integer_vif.c, whose padding is
+        reflect-101; VMAF_feature_vif_* (vmaf_float_*) names float_vif / vif_tools.c (include/pqa_vmaf.h)."""
+        return 1 if self.is_integer else 0
+
+    @property
     def vif_enhn_gain_limit(self) -> float:
         return _opt(self.main, "vif_enhn_gain_limit")
 

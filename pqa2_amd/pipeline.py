@@ -52,7 +52,8 @@ def score_files(reference_path: str, distorted_path: str, model: str | None = "v
     eng = make(ri.width, ri.height, bit_depth=ri.bit_depth, n_planes=n_planes,
                chroma_shift=(ri.hshift, ri.vshift), features=feats, device=device, max_batch=max_batch,
                result_capacity=max(b - a, 16), n_subsample=n_subsample,
-               vif_enhn_gain_limit=mdl.vif_enhn_gain_limit, adm_enhn_gain_limit=mdl.adm_enhn_gain_limit)
+               vif_enhn_gain_limit=mdl.vif_enhn_gain_limit, adm_enhn_gain_limit=mdl.adm_enhn_gain_limit,
+               vif_border=mdl.vif_border)
     try:
         if a > 0:
             eng.set_motion_halo(ref_rd.frame(a - 1)[0])   # one-frame halo in front of this rank's chunk

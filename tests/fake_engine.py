@@ -10,10 +10,10 @@ from pqa2_amd import _native as N
 class OracleEngine:
     def __init__(self, width, height, bit_depth=8, n_planes=1, chroma_shift=(1, 1), features=N.FEAT_VMAF,
                  device=0, max_batch=8, result_capacity=16384, n_subsample=1,
-                 vif_enhn_gain_limit=100.0, adm_enhn_gain_limit=100.0):
+                 vif_enhn_gain_limit=100.0, adm_enhn_gain_limit=100.0, vif_border=0):
         self.o = Oracle("f32")
         self.bpc, self.n_planes, self.features, self.k = bit_depth, n_planes, features, max(1, n_subsample)
-        self.gl = (vif_enhn_gain_limit, adm_enhn_gain_limit)
+        self.gl = (vif_enhn_gain_limit, adm_enhn_gain_limit, bool(vif_border))
         self.rec, self.prev_blur, self.cancelled = {}, None, False
 
     def set_motion_halo(self, prev):

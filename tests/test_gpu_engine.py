@@ -39,7 +39,8 @@ def test_analyzer_scores_match_oracle(tmp_path, oracle32, w, h, bpc, model):
     mdl = M.load_model(model)
     rec = np.zeros((n, 24))
     rec[:, :17] = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc,
-                                         vif_gain_limit=mdl.vif_enhn_gain_limit, adm_gain_limit=mdl.adm_enhn_gain_limit)
+                                         vif_gain_limit=mdl.vif_enhn_gain_limit, adm_gain_limit=mdl.adm_enhn_gain_limit,
+                                         vif_border101=bool(mdl.vif_border))
     want = M.score_frames(mdl, M.metrics_from_records(rec, w, h, "integer_"))
     got = res["raw_results"]["frames"]
     dv = max(abs(got[i]["metrics"]["vmaf"] - want["vmaf"][i]) for i in range(n))

@@ -49,6 +49,25 @@ def test_vmaf_features_8bit(oracle32, oracle64, w, h):
     assert got[0, 16] == 0.0
 
 
+@pytest.mark.parametrize("w,h,bpc", [(64, 48, 8), (321, 241, 8), (130, 18, 8), (16, 16, 8), (200, 120, 10)])
+def test_vif_integer_border(oracle64, w, h, bpc):
+    """pqa_config.vif_border = PQA_VIF_BORDER_INTEGER: integer_vif.c's reflect-101 padding (what the default
+    models' extractor uses); ADM and motion are untouched by the switch."""
+    from pqa2_amd import _native as N
+    n = 2
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
+    exp = _oracle_clip(oracle64, refs, diss, bpc, vif_border101=True)
+    exp_float = _oracle_clip(oracle64, refs, diss, bpc)
+    assert np.abs(exp[:, :8] - exp_float[:, :8]).max() > 0 and np.array_equal(exp[:, 8:], exp_float[:, 8:])
+    with _engine(w, h, bit_depth=bpc, vif_border=N.VIF_BORDER_INTEGER) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        got = eng.collect(0, n)[:, :17]
+    rel = np.abs(got[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-12)
+    assert rel.max() < REL_TOL, f"feature mismatch at {np.unravel_index(rel.argmax(), rel.shape)}"
+    assert np.abs(got[:, 16] - exp[:, 16]).max() < MOTION_ATOL
+
+
 @pytest.mark.parametrize("bpc", [10, 12])
 def test_vmaf_features_hbd(oracle64, bpc):
     w, h, n = 200, 120, 3

@@ -38,6 +38,8 @@ def test_models_load_unchanged_and_predict_matches_loop_restatement():
     assert neg.vif_enhn_gain_limit == 1.0 and neg.adm_enhn_gain_limit == 1.0
     assert M.load_model("vmaf_v0.6.1").main.metric_keys[0] == "integer_adm2"
     assert M.load_model("vmaf_float_v0.6.1").main.metric_keys[0] == "adm2"
+    # VIF padding follows the extractor the model names: integer_vif.c (reflect-101) vs vif_tools.c
+    assert [M.load_model(n).vif_border for n in ("vmaf_v0.6.1", "vmaf_4k_v0.6.1", "vmaf_float_v0.6.1")] == [1, 1, 0]
     b = M.load_model("vmaf_b_v0.6.3")
     assert len(b.models) == 21
     with pytest.raises(FileNotFoundError):
@@ -127,7 +129,7 @@ def test_analyzer_boundary_contract(tmp_path, oracle32):
     for k in ("integer_adm2", "integer_motion2", "integer_vif_scale0", "integer_vif_scale3", "vmaf", "psnr_y", "ssim"):
         assert k in fr[0]["metrics"]
     # scores are what the oracle + model give for these files
-    rec = np.zeros((4, 24)); rec[:, :17] = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], 8)
+    rec = np.zeros((4, 24)); rec[:, :17] = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], 8, vif_border101=True)
     want = M.score_frames(M.load_model("vmaf_v0.6.1"), M.metrics_from_records(rec, 96, 64, "integer_"))["vmaf"]
     np.testing.assert_allclose([f["metrics"]["vmaf"] for f in fr], want, atol=1e-6)
     # stats files hold one FFmpeg-format line per frame

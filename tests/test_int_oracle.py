@@ -1,0 +1,92 @@
+"""The fixed-point restatement (oracle/vmaf_int_oracle.c) against the float oracle and closed forms.
+
+Both are PARITY UNPINNED restatements of libvmaf (no libvmaf offline); what this file pins is their mutual
+consistency: two separately written versions of each extractor -- one in f32/f64, one in libvmaf's Q formats
+with its rounding constants -- must agree to the quantisation level of those Q formats.  A wrong shift, a wrong
+final scale factor (2^52, 2^45 ...) or a wrong border would show up as a gross mismatch here.
+"""
+import numpy as np
+import pytest
+
+from oracle.int_oracle import IntOracle
+from oracle.oracle import finish_features
+from pqa2_amd import model as M
+from pqa2_amd import synth
+
+
+@pytest.fixture(scope="module")
+def into():
+    return IntOracle()
+
+
+def _clip(w, h, n, bpc=8):
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
+    return [r[0] for r in refs], [d[0] for d in diss]
+
+
+def test_tables(into):
+    # log2 LUT: round(log2f(i) * 2048) on [32767, 65535]
+    assert into.lib.orc_int_log2_entry(32768) == 15 * 2048 and into.lib.orc_int_log2_entry(65535) == 32768
+    assert into.lib.orc_int_log2_entry(49152) == round(np.log2(49152.0) * 2048)
+
+
+@pytest.mark.parametrize("w,h,bpc", [(176, 144, 8), (321, 241, 8), (200, 120, 10)])
+def test_fixed_point_agrees_with_float_restatement(into, oracle64, w, h, bpc):
+    R, D = _clip(w, h, 3, bpc)
+    fi = into.clip_features(R, D, bpc)
+    ff = oracle64.clip_features(R, D, bpc, vif_border101=True)   # same VIF padding as integer_vif.c
+    a, b = finish_features(fi, w, h), finish_features(ff, w, h)
+    # Q8 means / Q16 variances + a 2048-step log2 LUT on the top 16 bits: ~1e-4 on a VIF scale
+    for s in range(4):
+        np.testing.assert_allclose(a[f"vif_scale{s}"], b[f"vif_scale{s}"], rtol=2e-4)
+    # Q6 int16 bands at scale 0, Q21/Q19/Q18 int32 deeper: ~1e-4
+    for s in range(4):
+        np.testing.assert_allclose(a[f"adm_scale{s}"], b[f"adm_scale{s}"], rtol=1.5e-4)
+    np.testing.assert_allclose(a["adm2"], b["adm2"], rtol=1e-4)
+    # Q8 blurred planes: the SAD mean moves by ~1e-5 of a grey level
+    np.testing.assert_allclose(a["motion"], b["motion"], rtol=2e-5, atol=1e-4)
+    # ... and the scores those features give differ by well under the 0.01 VMAF target
+    mdl = M.load_model("vmaf_v0.6.1")
+    def vmaf(rec):
+        full = np.zeros((rec.shape[0], 24)); full[:, :17] = rec
+        return M.score_frames(mdl, M.metrics_from_records(full, w, h))["vmaf"]
+    assert np.abs(vmaf(fi) - vmaf(ff)).max() < 0.01
+
+
+def test_border_rule_is_what_separates_the_two_vif_extractors(into, oracle64):
+    """With vif_tools.c's border the float VIF sits several 1e-4 from the fixed-point one at CIF size; with
+    integer_vif.c's padding the residual is quantisation only.  This is why pqa_config.vif_border exists."""
+    w, h = 352, 288
+    R, D = _clip(w, h, 1)
+    vi = into.vif(R[0], D[0])
+    v101 = oracle64.clip_features(R, D, 8, vif_border101=True)[0, :8]
+    vrep = oracle64.clip_features(R, D, 8)[0, :8]
+    r101 = np.abs(vi[:4] / vi[4:] - v101[:4] / v101[4:]).max()
+    rrep = np.abs(vi[:4] / vi[4:] - vrep[:4] / vrep[4:]).max()
+    assert r101 < 1e-4 and rrep > 3 * r101
+
+
+def test_motion_closed_forms(into):
+    R, _ = _clip(96, 64, 2)
+    b0 = into.motion_blur(R[0])
+    assert into.motion_sad(b0, b0) == 0
+    # a constant plane blurs to the constant in Q8 exactly (taps sum to 65536)
+    c = np.full((32, 48), 77, np.uint8)
+    assert np.all(into.motion_blur(c) == 77 * 256)
+    c10 = np.full((32, 48), 613, np.uint16)
+    assert np.all(into.motion_blur(c10, 10) == 613 * 64)
+    # +1 grey level everywhere -> motion exactly 1
+    c2 = np.full((32, 48), 78, np.uint8)
+    sad = into.motion_sad(into.motion_blur(c), into.motion_blur(c2))
+    assert into.motion_score(sad, 48, 32) == 1.0
+
+
+def test_identical_frames(into):
+    R, _ = _clip(128, 96, 1)
+    v = into.vif(R[0], R[0])
+    a = into.adm(R[0], R[0])
+    # fixed-point VIF of identical frames is a hair under 1 (g = s/(s+eps) and truncations); ADM's numerator uses
+    # the Q21 weight, its denominator the float one: equal to 1e-5
+    np.testing.assert_allclose(v[:4] / v[4:], 1.0, atol=2e-4)
+    assert np.all(v[:4] <= v[4:])
+    np.testing.assert_allclose(a[:4] / a[4:], 1.0, atol=2e-5)
