@@ -56,7 +56,7 @@ def test_analyzer_scores_match_oracle(tmp_path, oracle32, w, h, bpc, model):
     assert open(res["psnr_log"]).read().split("\n")[:-1] == report.psnr_stats_lines(sse, sizes, bpc)
 
 
-@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160), (4098, 2162), (7680, 4320)])
 def test_full_size_properties(w, h):
     """BASELINE sizes, checked through properties that need no oracle pass:
     identical -> vif/adm == 1, SSE == 0; static -> motion == 0; +c offset -> SSE == c^2*W*H and a
