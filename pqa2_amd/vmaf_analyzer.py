@@ -307,7 +307,7 @@ class VMAFAnalyzer(QObject):
         state = {"t": time.time()}
         stderr_lines = []
         try:
-            self._current_process = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+            self._current_process = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
                                                      bufsize=1, env=env)
             for line in iter(self._current_process.stderr.readline, ""):
                 if self._terminate_requested:

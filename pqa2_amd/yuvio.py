@@ -130,6 +130,22 @@ class Y4MReader:
     def __len__(self):
         return self.info.n_frames
 
+    def close(self):
+        """Drops the mapping; removes the file too when it is a temporary decode (_decode_with_ffmpeg)."""
+        self._mm = None
+        tmp, self._tempfile = getattr(self, "_tempfile", None), None
+        if tmp:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def frame(self, i: int):
         """Planes [Y, U, V] (or [Y]) of frame i as read-only arrays viewing the mapped file."""
         info = self.info
@@ -205,20 +221,45 @@ def open_video(path: str, **raw_kwargs):
     return _decode_with_ffmpeg(path)
 
 
+_DECODED: dict = {}   # (path, mtime, size) -> Y4MReader over the temporary decode; a run opens each clip several times
+
+
+def _drop_decodes():
+    while _DECODED:
+        _DECODED.popitem()[1].close()
+
+
+import atexit  # noqa: E402
+atexit.register(_drop_decodes)
+
+
 def _decode_with_ffmpeg(path: str):
     """Compressed containers need a decoder; the reference relies on ffmpeg for that too
-    (app/vmaf_analyzer.py:411-419).  Only the *decode* is delegated -- never the metric filters."""
+    (app/vmaf_analyzer.py:411-419).  Only the *decode* is delegated -- never the metric filters.
+    The decode is kept (at most 4 clips) because one analysis opens each clip for metadata and for scoring."""
     import shutil
     import subprocess
     import tempfile
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    rd = _DECODED.get(key)
+    if rd is not None and rd._mm is not None:
+        return rd
     exe = shutil.which("ffmpeg")
     if not exe:
         raise RuntimeError(
             f"cannot decode {os.path.basename(path)}: no ffmpeg on PATH; supply .y4m or raw .yuv input")
     tmp = tempfile.NamedTemporaryFile(suffix=".y4m", delete=False)
     tmp.close()
-    subprocess.run([exe, "-hide_banner", "-loglevel", "error", "-y", "-i", path, "-f", "yuv4mpegpipe",
-                    "-strict", "-1", tmp.name], check=True)
-    rd = Y4MReader(tmp.name)
+    try:
+        subprocess.run([exe, "-hide_banner", "-loglevel", "error", "-y", "-i", path, "-f", "yuv4mpegpipe",
+                        "-strict", "-1", tmp.name], check=True)
+        rd = Y4MReader(tmp.name)
+    except Exception:
+        os.unlink(tmp.name)
+        raise
     rd._tempfile = tmp.name
+    while len(_DECODED) >= 4:
+        _DECODED.pop(next(iter(_DECODED))).close()
+    _DECODED[key] = rd
     return rd

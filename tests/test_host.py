@@ -108,6 +108,35 @@ def _analyzer(tmp_path):
     return a, ev
 
 
+def test_compressed_input_is_decoded_once_by_a_system_ffmpeg(tmp_path, monkeypatch):
+    """Anything that is not .y4m/.yuv goes through `ffmpeg -f yuv4mpegpipe` (decode only, as the reference's
+    ffmpeg child decodes, app/vmaf_analyzer.py:411-419).  No ffmpeg exists here, so a stand-in script that
+    copies a prepared Y4M plays its part; the decode is cached per clip and the temp file removed on close."""
+    refs, _ = synth.make_clip(64, 48, 2, 8)
+    src = str(tmp_path / "a.y4m")
+    yuvio.write_y4m(src, refs, synth.clip_info(64, 48))
+    mp4 = str(tmp_path / "a.mp4")
+    with open(mp4, "wb") as f:
+        f.write(b"\x00\x00\x00\x18ftypmp42")
+    with pytest.raises(RuntimeError, match="no ffmpeg on PATH"):
+        monkeypatch.setenv("PATH", str(tmp_path / "empty"))
+        yuvio.open_video(mp4)
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    fake = bindir / "ffmpeg"
+    fake.write_text(f'#!/bin/sh\nfor a; do last="$a"; done\ncp {src} "$last"\n')
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + "/usr/bin" + os.pathsep + "/bin")
+    r1 = yuvio.open_video(mp4)
+    assert yuvio.open_video(mp4) is r1 and len(r1) == 2 and np.array_equal(r1.frame(1)[0], refs[1][0])
+    tmp = r1._tempfile
+    assert os.path.exists(tmp)
+    r1.close()
+    assert not os.path.exists(tmp)
+    assert yuvio.open_video(mp4) is not r1
+    yuvio._drop_decodes()
+
+
 def test_analyzer_boundary_contract(tmp_path, oracle32):
     rp, dp, refs, diss = _write_pair(tmp_path)
     a, ev = _analyzer(tmp_path)
