@@ -53,6 +53,14 @@ def _sep(x: np.ndarray, taps: np.ndarray) -> np.ndarray:
     return _corr_axis(_corr_axis(x, taps, 0), taps, 1)
 
 
+def _sep101(x: np.ndarray, taps: np.ndarray) -> np.ndarray:
+    """Same separable filter with integer_vif.c's padding: reflect-101 on all four edges (numpy's 'reflect')."""
+    r = len(taps) // 2
+    p = np.pad(x, r, mode="reflect")
+    v = sum(c * p[k: k + x.shape[0], :] for k, c in enumerate(taps))
+    return sum(c * v[:, k: k + x.shape[1]] for k, c in enumerate(taps))
+
+
 def picture_copy(plane: np.ndarray, bpc: int) -> np.ndarray:
     x = plane.astype(np.float64)
     if bpc > 8:
@@ -60,8 +68,9 @@ def picture_copy(plane: np.ndarray, bpc: int) -> np.ndarray:
     return x - 128.0
 
 
-def vif(ref: np.ndarray, dis: np.ndarray, gain_limit: float = 100.0):
+def vif(ref: np.ndarray, dis: np.ndarray, gain_limit: float = 100.0, border101: bool = False):
     """(num[4], den[4]) from picture_copy'd planes."""
+    _sep = _sep101 if border101 else globals()["_sep"]
     num, den = np.zeros(4), np.zeros(4)
     for s, n in enumerate((17, 9, 5, 3)):
         f = gaussian_taps(n)

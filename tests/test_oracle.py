@@ -58,6 +58,19 @@ def test_hbd_and_gain_limit_agree_with_numpy(oracle64):
     np.testing.assert_allclose(f64, fn, rtol=5e-8, atol=1e-10)
 
 
+def test_vif_integer_padding_agrees_with_numpy(oracle64):
+    """vif_border101 (integer_vif.c's reflect-101 padding) in the C oracle vs np.pad(mode='reflect')."""
+    for (w, h) in ((120, 72), (33, 21)):
+        refs, diss = synth.make_clip(w, h, 1, 8, chroma=False)
+        f64, _ = oracle64.frame_features(refs[0][0], diss[0][0], 8, None, vif_border101=True)
+        num, den = NP.vif(NP.picture_copy(refs[0][0], 8), NP.picture_copy(diss[0][0], 8), border101=True)
+        np.testing.assert_allclose(f64[0:4], num, rtol=5e-8)
+        np.testing.assert_allclose(f64[4:8], den, rtol=5e-8)
+        plain, _ = oracle64.frame_features(refs[0][0], diss[0][0], 8, None)
+        assert np.abs(plain[0:4] / f64[0:4] - 1).max() > 1e-5      # the two paddings do differ
+        np.testing.assert_array_equal(plain[8:], f64[8:])          # and only VIF is affected
+
+
 def test_closed_forms(oracle32):
     refs, _ = synth.make_clip(96, 64, 1, 8, chroma=True)
     y = refs[0][0]
