@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--vif-fixed", action="store_true",
+                    help="measure the fixed-point VIF mode (integer_vif.c arithmetic) instead of the default f32 path")
     args = ap.parse_args()
 
     import torch
@@ -107,7 +109,8 @@ def main():
     eng = FeatureEngine(w, h, bit_depth=bpc, n_planes=n_planes, features=feats, device=local_rank,
                         max_batch=args.batch, result_capacity=max(F, 1024),
                         vif_enhn_gain_limit=model.vif_enhn_gain_limit,
-                        adm_enhn_gain_limit=model.adm_enhn_gain_limit, vif_border=model.vif_border)
+                        adm_enhn_gain_limit=model.adm_enhn_gain_limit, vif_border=model.vif_border,
+                        vif_fixed=args.vif_fixed)
     prefix = "integer_" if model.is_integer else ""
     result = {}
 
@@ -161,9 +164,10 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not args.vif_fixed else "f32 (ADM, motion) + u16/u32/u64 fixed-point VIF", "data": "synthetic",
             "config": {"workload": f"{args.workload} {w}x{h} {bpc}-bit, {model_name}, {F} frames/GPU"
-                                   f"{' + PSNR/SSIM all planes' if side else ''}",
+                                   f"{' + PSNR/SSIM all planes' if side else ''}"
+                                   f"{' [--vif-fixed: integer_vif.c arithmetic for VIF]' if args.vif_fixed else ''}",
                        "frames_per_gpu": F, "frames_total": total, "batch": args.batch,
                        "parallelism": f"frame-shard x{world}, 1-frame motion halo, all-gather of records + of scores"},
             "pooled_vmaf_mean": round(result["pooled"]["mean"], 6),
@@ -173,9 +177,10 @@ def main():
             avg_ms = k["ms"] / k["launches"]
             frames_per_launch = k["frames"] / k["launches"]
             achieved = b_alg * frames_per_launch / (avg_ms * 1e-3) / 1e9
-            per_frame = _traffic_from_profiles(args.workload)
+            per_frame = None if args.vif_fixed else _traffic_from_profiles(args.workload)
             traffic = int(per_frame * frames_per_launch) if per_frame else None
-            out["roofline"] = {"bound": "hbm", "kernel": "vif_stat_kernel<u8,17,240,9> (VIF scale 0 + fused decimation to scale 1)",
+            kname = ("vif_fixed_kernel" if args.vif_fixed else "vif_stat_kernel") + f"<{'u8' if bpc == 8 else 'u16'},17,240,9>"
+            out["roofline"] = {"bound": "hbm", "kernel": kname + " (VIF scale 0 + fused decimation to scale 1)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5),
                                "traffic": traffic,
@@ -185,7 +190,7 @@ def main():
                                           for name, v in breakdown.items() if v["launches"]}
             out["kernel_ms_note"] = "from one extra untimed pass with every kernel event-timed (ms per frame)"
 
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.vif_fixed:  # the CPU leg times the float restatement
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             n_sample = args.cpu_sample_frames or max(2, min(F, threads * max(1, int(12.0 / (w * h * 2.0e-7)))))
             out["cpu_baseline"] = _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads,

@@ -84,14 +84,17 @@ typedef struct pqa_config {
   double vif_enhn_gain_limit;  /* 100.0 default; 1.0 for *neg models (feature_opts_dicts)         */
   double adm_enhn_gain_limit;  /* 100.0 default; 1.0 for *neg models                              */
   uint32_t vif_border;         /* PQA_VIF_BORDER_*: which libvmaf extractor's VIF padding to follow  */
-  uint32_t reserved0;          /* must be 0                                                       */
+  uint32_t vif_fixed;          /* 1: VIF in integer_vif.c's fixed-point arithmetic (implies the integer
+                                  border); 0: f32 arithmetic (the fast path, the default)            */
 } pqa_config;
 
 /* libvmaf has two VIF extractors with different image-border handling.  `model=version=vmaf_v0.6.1`
  * (app/vmaf_analyzer.py:377) names VMAF_integer_feature_vif_* (models/vmaf_v0.6.1.json:31-38), i.e.
  * integer_vif.c, which pads by reflect-101 on all four edges; the vmaf_float_* models name float_vif
  * (vif_tools.c), which repeats the edge sample at the bottom/right edge.  The arithmetic here is f32 in
- * both cases (DESIGN.md "float vs fixed-point" quantifies the residual); this selects the border only. */
+ * both cases (DESIGN.md "float vs fixed-point" quantifies the residual); this selects the border only.
+ * pqa_config.vif_fixed = 1 goes the whole way for VIF: Q16 taps, Q8 means, 2048-step log2 table, integer
+ * accumulators (csrc/vif_fixed.hip), bit-identical to oracle/vmaf_int_oracle.c at about half the speed. */
 enum {
   PQA_VIF_BORDER_FLOAT = 0,   /* vif_tools.c:   index -i -> i,  n-1+i -> n-i    */
   PQA_VIF_BORDER_INTEGER = 1  /* integer_vif.c: index -i -> i,  n-1+i -> n-1-i  */

@@ -34,7 +34,7 @@ class PqaConfig(C.Structure):
         ("chroma_vshift", C.c_uint32), ("features", C.c_uint32), ("max_batch", C.c_uint32),
         ("result_capacity", C.c_uint32), ("n_subsample", C.c_uint32),
         ("vif_enhn_gain_limit", C.c_double), ("adm_enhn_gain_limit", C.c_double),
-        ("vif_border", C.c_uint32), ("reserved0", C.c_uint32),
+        ("vif_border", C.c_uint32), ("vif_fixed", C.c_uint32),
     ]
 
 

@@ -25,7 +25,31 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) 
   double* rec = a.records + (int64_t)row * a.record_stride;
   const int tid = threadIdx.x;
 
-  if (a.has_vif && grp < 4) {
+  if (a.has_vif && grp < 4 && a.vif_fx_part[grp]) {
+    // integer_vif.c epilogue: exact integer sums over the tiles, then the two doubles exactly as the C code
+    // forms them (operation by operation, no fused multiply-add)
+#pragma clang fp contract(off)
+    const int s = grp;
+    const long long* p = a.vif_fx_part[s] + (int64_t)fr * a.vif_tiles[s] * kVifFxPartials;
+    long long q[7];
+    for (int i = 0; i < 7; ++i) {
+      long long v = 0;
+      for (int t = tid; t < a.vif_tiles[s]; t += kBlock) v += p[(int64_t)t * kVifFxPartials + i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      __syncthreads();
+      if ((tid & 63) == 0) redu[tid >> 6] = (unsigned long long)v;
+      __syncthreads();
+      q[i] = (long long)((redu[0] + redu[1]) + (redu[2] + redu[3]));
+    }
+    if (tid == 0) {
+      const long long num_log = q[0], den_log = q[1], x = q[2], x2 = q[3], n_log = q[4], den_non_log = q[5],
+                      num_non_log = q[6];
+      rec[0 + s] = (double)num_log / 2048.0 + (double)x2 +
+                   ((double)den_non_log - ((double)num_non_log / 16384.0) / 65025.0);
+      rec[4 + s] = (double)den_log / 2048.0 - (double)(x + n_log * 17) + (double)den_non_log;
+    }
+  } else if (a.has_vif && grp < 4) {
     {
       const int s = grp;
       const double* p = a.vif_part[s] + (int64_t)fr * a.vif_tiles[s] * 2;

@@ -38,6 +38,15 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
                            int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
                            MutPlaneRun next_ref, MutPlaneRun next_dis);
 
+// Fixed-point VIF (integer_vif.c arithmetic, vif_fixed.hip): same tiling; partials are [n_frames][tiles][8] int64
+// {num_log, den_log, x, x2, n_log, den_non_log, num_non_log, -}; next_ref / next_dis are u16 planes (w/2 x h/2).
+// elem: scale 0 reads the caller's samples (ELEM_U8 at 8 bit, ELEM_U16 above), deeper scales ELEM_U16.
+constexpr int kVifFxPartials = 8;
+void vif_fixed_log2_table(uint16_t* out32768);  // host: entry i = round(log2f(32768 + i) * 2048)
+hipError_t launch_vif_fixed(hipStream_t stream, int scale, int bit_depth, Elem elem, PlaneRun ref, PlaneRun dis,
+                            int n_frames, int w, int h, double gain_limit, const uint16_t* log2_lut,
+                            long long* partials, MutPlaneRun next_ref, MutPlaneRun next_dis);
+
 // ---- ADM ------------------------------------------------------------------------------------
 constexpr int kAdmTileW = 60, kAdmTileH = 14;  // 126 input columns (one per lane), 16 halo'd rows = 8 row pairs
 inline int adm_tiles_x(int band_w) { return (band_w + kAdmTileW - 1) / kAdmTileW; }
@@ -92,6 +101,7 @@ struct FinalizeArgs {
   int n_frames;
   int has_vif, has_adm, has_motion, n_sse_planes, n_ssim_planes;
   const double* vif_part[4];   int vif_tiles[4];
+  const long long* vif_fx_part[4];            // non-null: fixed-point VIF partials (kVifFxPartials int64 per tile)
   const double* adm_part[4];   int adm_tiles[4];   float adm_area[4];  // cropped-window area per scale
   const double* motion_part;   int motion_tiles;   double motion_norm;  // 2^-(bpc-8) / (w*h)
   const unsigned long long* sse_part[3];      // [n_frames][kSseBlocksPerPlane]: whole plane, or the right strip

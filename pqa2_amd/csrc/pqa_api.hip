@@ -54,6 +54,9 @@ struct pqa_ctx {
   int B = 8, HB = 8, capacity = 16384, k_sub = 1;  // B: frames per launch; HB: frames per host-staging half
   Level vif_lv[4], adm_lv[4];
   double* vif_part[4] = {};
+  long long* vif_fx_part[4] = {};  // fixed-point VIF: int64 partials instead of (num, den) doubles
+  uint16_t* vif_lut = nullptr;     // integer_vif.c's log2 table, entries 32768..65535
+  bool vif_fixed = false;
   int vif_tiles[4] = {};
   double* adm_part[4] = {};
   int adm_tiles[4] = {};
@@ -201,7 +204,31 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   };
   const PlaneRun rYs = k > 1 ? sub(rY) : rY, dYs = k > 1 ? sub(dY) : dY;
 
-  if ((feat & PQA_FEAT_VIF) && sp_n > 0) {
+  if ((feat & PQA_FEAT_VIF) && sp_n > 0 && c->vif_fixed) {
+    PlaneRun cr = rYs, cd = dYs;
+    Elem ce = c->elem;
+    int cw = w, ch = h;
+    for (int s = 0; s < 4; ++s) {
+      MutPlaneRun nr{nullptr, 0, 0}, nd{nullptr, 0, 0};
+      if (s < 3) {  // the pyramid buffers hold u16 planes in this mode (same element pitches, half the bytes)
+        Level& L = c->vif_lv[s + 1];
+        nr = MutPlaneRun{L.ref, L.pitch, L.frame_pitch};
+        nd = MutPlaneRun{L.dis, L.pitch, L.frame_pitch};
+      }
+      {
+        ProfScope ps(c, s, sp_n, st);
+        HIPCHK(c, launch_vif_fixed(st, s, (int)c->cfg.bit_depth, ce, cr, cd, sp_n, cw, ch, c->cfg.vif_enhn_gain_limit,
+                                   c->vif_lut, c->vif_fx_part[s], nr, nd));
+      }
+      if (s < 3) {
+        Level& L = c->vif_lv[s + 1];
+        cr = PlaneRun{L.ref, L.pitch, L.frame_pitch};
+        cd = PlaneRun{L.dis, L.pitch, L.frame_pitch};
+        ce = ELEM_U16;
+        cw = L.w; ch = L.h;
+      }
+    }
+  } else if ((feat & PQA_FEAT_VIF) && sp_n > 0) {
     PlaneRun cr = rYs, cd = dYs;
     Elem ce = c->elem;
     int cw = w, ch = h;
@@ -316,6 +343,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   FinalizeArgs fa{};
   for (int s = 0; s < 4; ++s) {
     fa.vif_part[s] = c->vif_part[s]; fa.vif_tiles[s] = c->vif_tiles[s];
+    fa.vif_fx_part[s] = c->vif_fixed ? c->vif_fx_part[s] : nullptr;
     fa.adm_part[s] = c->adm_part[s]; fa.adm_tiles[s] = c->adm_tiles[s]; fa.adm_area[s] = c->adm_area[s];
   }
   fa.motion_part = c->motion_part; fa.motion_tiles = c->motion_tiles_n;
@@ -454,8 +482,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   if (cfg->chroma_hshift > 2 || cfg->chroma_vshift > 2) return fail(nullptr, PQA_EINVAL, "bad chroma shift");
   if ((cfg->features & ~(uint32_t)PQA_FEAT_ALL) || cfg->features == 0)
     return fail(nullptr, PQA_EINVAL, "bad feature mask 0x%x", cfg->features);
-  if (cfg->vif_border > PQA_VIF_BORDER_INTEGER || cfg->reserved0 != 0)
-    return fail(nullptr, PQA_EINVAL, "bad vif_border %u", cfg->vif_border);
+  if (cfg->vif_border > PQA_VIF_BORDER_INTEGER || cfg->vif_fixed > 1)
+    return fail(nullptr, PQA_EINVAL, "bad vif_border %u / vif_fixed %u", cfg->vif_border, cfg->vif_fixed);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, PQA_EDEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -512,6 +540,13 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   }
   CREATE_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
 
+  c->vif_fixed = (cfg->features & PQA_FEAT_VIF) && cfg->vif_fixed;
+  if (c->vif_fixed) {
+    std::vector<uint16_t> lut(32768);
+    vif_fixed_log2_table(lut.data());
+    CREATE_TRY(dev_alloc(c, &c->vif_lut, lut.size()));
+    CREATE_HIP(hipMemcpy(c->vif_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
   const int w = c->pw[0], h = c->ph[0], B = c->B;
   // VIF pyramid (floor halving) and ADM approximation bands (ceil halving), f32, rows padded to 64 B
   int vw = w, vh = h, aw = w, ah = h;
@@ -538,7 +573,10 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     c->adm_tiles[s] = adm_tiles_x(bw) * adm_tiles_y(bh);
     const int left = (int)(bw * 0.1 - 0.5), top = (int)(bh * 0.1 - 0.5);
     c->adm_area[s] = (float)((bh - 2 * top) * (bw - 2 * left));
-    if (cfg->features & PQA_FEAT_VIF) CREATE_TRY(dev_alloc(c, &c->vif_part[s], (size_t)c->vif_tiles[s] * 2 * B));
+    if ((cfg->features & PQA_FEAT_VIF) && !c->vif_fixed)
+      CREATE_TRY(dev_alloc(c, &c->vif_part[s], (size_t)c->vif_tiles[s] * 2 * B));
+    if ((cfg->features & PQA_FEAT_VIF) && c->vif_fixed)
+      CREATE_TRY(dev_alloc(c, &c->vif_fx_part[s], (size_t)c->vif_tiles[s] * kVifFxPartials * B));
     if (cfg->features & PQA_FEAT_ADM) CREATE_TRY(dev_alloc(c, &c->adm_part[s], (size_t)c->adm_tiles[s] * 6 * B));
   }
   c->motion_tiles_n = motion_tiles(w, h);

@@ -120,6 +120,40 @@ def test_one_oracle_frame_at_1080p(oracle32):
     assert rel.max() < 5e-5 and abs(got[1, 16] - exp[1, 16]) < 5e-6 * exp[1, 16] + 2e-5
 
 
+def test_fixed_point_vif_at_1080p_and_through_the_analyzer(tmp_path):
+    """vif_fixed at a BASELINE size: bit-equal to the fixed-point restatement on full frames (edge tiles, all four
+    scales, several launches), and reachable through VMAFAnalyzer (`vif_fixed_point`)."""
+    from oracle.int_oracle import IntOracle
+    from pqa2_amd.engine import FeatureEngine
+    from pqa2_amd.vmaf_analyzer import VMAFAnalyzer
+    into = IntOracle()
+    w, h = 1920, 1080
+    refs, diss = synth.make_clip(w, h, 3, 8, chroma=False)
+    want = np.stack([into.vif(refs[i][0], diss[i][0]) for i in range(3)])
+    with FeatureEngine(w, h, vif_fixed=True, max_batch=2) as eng:
+        for i in range(3):
+            eng.submit(i, refs[i], diss[i])
+        got = eng.collect(0, 3)
+    assert np.array_equal(got[:, :8].view(np.uint64), want.view(np.uint64))
+    # analyzer: same files scored in both arithmetic modes differ by the quantisation residual only
+    rp, dp, r2, d2 = _pair(tmp_path, 352, 288, 4, 8)
+    scores = {}
+    for fixed in (False, True):
+        a = VMAFAnalyzer()
+        a.set_output_directory(str(tmp_path))
+        a.set_test_name("fx" if fixed else "fl")
+        a.vif_fixed_point = fixed
+        res = a.analyze_videos(rp, dp, "vmaf_v0.6.1")
+        assert res is not None
+        scores[fixed] = res
+    fx_frames = scores[True]["raw_results"]["frames"]
+    want_small = [into.vif(r2[i][0], d2[i][0]) for i in range(4)]
+    for i in range(4):
+        for s_ in range(4):
+            assert abs(fx_frames[i]["metrics"][f"integer_vif_scale{s_}"] - want_small[i][s_] / want_small[i][4 + s_]) < 1e-6
+    assert 0 < abs(scores[True]["vmaf_score"] - scores[False]["vmaf_score"]) < 0.01
+
+
 def test_score_cli_single_and_torchrun(tmp_path):
     """python -m pqa2_amd.score, plain and under torch.distributed.run (1 rank on this 1-GPU box)."""
     import subprocess
