@@ -52,8 +52,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
-    ap.add_argument("--vif-fixed", action="store_true",
-                    help="measure the fixed-point VIF mode (integer_vif.c arithmetic) instead of the default f32 path")
+    ap.add_argument("--fixed-point", type=int, default=0,
+                    help="PQA_FIXED_* mask (1 VIF, 2 motion): measure libvmaf's fixed-point arithmetic instead of the "
+                         "default f32 path")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +111,7 @@ def main():
                         max_batch=args.batch, result_capacity=max(F, 1024),
                         vif_enhn_gain_limit=model.vif_enhn_gain_limit,
                         adm_enhn_gain_limit=model.adm_enhn_gain_limit, vif_border=model.vif_border,
-                        vif_fixed=args.vif_fixed)
+                        fixed_point=args.fixed_point)
     prefix = "integer_" if model.is_integer else ""
     result = {}
 
@@ -164,10 +165,10 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not args.vif_fixed else "f32 (ADM, motion) + u16/u32/u64 fixed-point VIF", "data": "synthetic",
+            "dtype": "f32" if not args.fixed_point else f"f32 + fixed-point extractors (mask {args.fixed_point})", "data": "synthetic",
             "config": {"workload": f"{args.workload} {w}x{h} {bpc}-bit, {model_name}, {F} frames/GPU"
                                    f"{' + PSNR/SSIM all planes' if side else ''}"
-                                   f"{' [--vif-fixed: integer_vif.c arithmetic for VIF]' if args.vif_fixed else ''}",
+                                   f"{f' [--fixed-point {args.fixed_point}: libvmaf integer arithmetic]' if args.fixed_point else ''}",
                        "frames_per_gpu": F, "frames_total": total, "batch": args.batch,
                        "parallelism": f"frame-shard x{world}, 1-frame motion halo, all-gather of records + of scores"},
             "pooled_vmaf_mean": round(result["pooled"]["mean"], 6),
@@ -177,9 +178,9 @@ def main():
             avg_ms = k["ms"] / k["launches"]
             frames_per_launch = k["frames"] / k["launches"]
             achieved = b_alg * frames_per_launch / (avg_ms * 1e-3) / 1e9
-            per_frame = None if args.vif_fixed else _traffic_from_profiles(args.workload)
+            per_frame = None if args.fixed_point & 1 else _traffic_from_profiles(args.workload)
             traffic = int(per_frame * frames_per_launch) if per_frame else None
-            kname = ("vif_fixed_kernel" if args.vif_fixed else "vif_stat_kernel") + f"<{'u8' if bpc == 8 else 'u16'},17,240,9>"
+            kname = ("vif_fixed_kernel" if args.fixed_point & 1 else "vif_stat_kernel") + f"<{'u8' if bpc == 8 else 'u16'},17,240,9>"
             out["roofline"] = {"bound": "hbm", "kernel": kname + " (VIF scale 0 + fused decimation to scale 1)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -190,7 +191,7 @@ def main():
                                           for name, v in breakdown.items() if v["launches"]}
             out["kernel_ms_note"] = "from one extra untimed pass with every kernel event-timed (ms per frame)"
 
-        if world == 1 and not args.no_cpu_baseline and not args.vif_fixed:  # the CPU leg times the float restatement
+        if world == 1 and not args.no_cpu_baseline and not args.fixed_point:  # the CPU leg times the float restatement
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             n_sample = args.cpu_sample_frames or max(2, min(F, threads * max(1, int(12.0 / (w * h * 2.0e-7)))))
             out["cpu_baseline"] = _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads,

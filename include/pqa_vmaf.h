@@ -84,8 +84,8 @@ typedef struct pqa_config {
   double vif_enhn_gain_limit;  /* 100.0 default; 1.0 for *neg models (feature_opts_dicts)         */
   double adm_enhn_gain_limit;  /* 100.0 default; 1.0 for *neg models                              */
   uint32_t vif_border;         /* PQA_VIF_BORDER_*: which libvmaf extractor's VIF padding to follow  */
-  uint32_t vif_fixed;          /* 1: VIF in integer_vif.c's fixed-point arithmetic (implies the integer
-                                  border); 0: f32 arithmetic (the fast path, the default)            */
+  uint32_t fixed_point;        /* PQA_FIXED_* mask: extractors to run in libvmaf's fixed-point arithmetic
+                                  instead of f32 (0 = none: the fast path, the default)              */
 } pqa_config;
 
 /* libvmaf has two VIF extractors with different image-border handling.  `model=version=vmaf_v0.6.1`
@@ -93,8 +93,10 @@ typedef struct pqa_config {
  * integer_vif.c, which pads by reflect-101 on all four edges; the vmaf_float_* models name float_vif
  * (vif_tools.c), which repeats the edge sample at the bottom/right edge.  The arithmetic here is f32 in
  * both cases (DESIGN.md "float vs fixed-point" quantifies the residual); this selects the border only.
- * pqa_config.vif_fixed = 1 goes the whole way for VIF: Q16 taps, Q8 means, 2048-step log2 table, integer
- * accumulators (csrc/vif_fixed.hip), bit-identical to oracle/vmaf_int_oracle.c at about half the speed. */
+ * pqa_config.fixed_point goes the whole way per extractor: PQA_FIXED_VIF = integer_vif.c (Q16 taps, Q8 means,
+ * 2048-step log2 table, integer accumulators; implies the integer border), PQA_FIXED_MOTION = integer_motion.c
+ * (Q8 blurred planes, integer SAD).  Bit-identical to oracle/vmaf_int_oracle.c; VIF runs at ~0.6x the f32 speed. */
+enum { PQA_FIXED_VIF = 1, PQA_FIXED_MOTION = 2, PQA_FIXED_ALL = 3 };
 enum {
   PQA_VIF_BORDER_FLOAT = 0,   /* vif_tools.c:   index -i -> i,  n-1+i -> n-i    */
   PQA_VIF_BORDER_INTEGER = 1  /* integer_vif.c: index -i -> i,  n-1+i -> n-1-i  */

@@ -14,6 +14,7 @@ FEAT_VIF, FEAT_ADM, FEAT_MOTION, FEAT_PSNR, FEAT_SSIM = 1, 2, 4, 8, 16
 FEAT_VMAF = FEAT_VIF | FEAT_ADM | FEAT_MOTION
 FEAT_ALL = FEAT_VMAF | FEAT_PSNR | FEAT_SSIM
 VIF_BORDER_FLOAT, VIF_BORDER_INTEGER = 0, 1  # pqa_config.vif_border (include/pqa_vmaf.h)
+FIXED_VIF, FIXED_MOTION, FIXED_ALL = 1, 2, 3   # pqa_config.fixed_point mask
 REC_VIF_NUM, REC_VIF_DEN, REC_ADM_NUM, REC_ADM_DEN, REC_MOTION, REC_SSIM, REC_SSE = 0, 4, 8, 12, 16, 17, 20
 RECORD_DOUBLES = 24
 PROF_KERNELS = 15
@@ -34,7 +35,7 @@ class PqaConfig(C.Structure):
         ("chroma_vshift", C.c_uint32), ("features", C.c_uint32), ("max_batch", C.c_uint32),
         ("result_capacity", C.c_uint32), ("n_subsample", C.c_uint32),
         ("vif_enhn_gain_limit", C.c_double), ("adm_enhn_gain_limit", C.c_double),
-        ("vif_border", C.c_uint32), ("vif_fixed", C.c_uint32),
+        ("vif_border", C.c_uint32), ("fixed_point", C.c_uint32),
     ]
 
 

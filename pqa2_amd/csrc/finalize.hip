@@ -73,7 +73,21 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) 
     }
   }
   if (grp != 8) return;
-  if (a.has_motion) {
+  if (a.has_motion && a.motion_fx_part) {
+    const unsigned long long* p = a.motion_fx_part + (int64_t)fr * a.motion_tiles;
+    unsigned long long v = 0;
+    for (int i = tid; i < a.motion_tiles; i += kBlock) v += p[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) redu[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {  // integer_motion.c normalize_and_scale_sad(): (float)(sad / 256.) / (w * h)
+      const unsigned long long sad = (redu[0] + redu[1]) + (redu[2] + redu[3]);
+      rec[16] = (double)((float)((double)sad / 256.0) / (float)a.motion_wh);
+    }
+    __syncthreads();
+  } else if (a.has_motion) {
     const double sad = reduce_strided(a.motion_part + (int64_t)fr * a.motion_tiles, a.motion_tiles, 1, red);
     if (tid == 0) rec[16] = sad * a.motion_norm;
   }

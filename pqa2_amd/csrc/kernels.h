@@ -70,6 +70,11 @@ inline int motion_tiles(int w, int h) {
 hipError_t launch_motion(hipStream_t stream, Elem elem, PlaneRun ref, const void* prev0, int64_t prev0_row_pitch,
                          int n_frames, int w, int h, float inv_scale, double* partials);
 
+// Fixed-point motion (integer_motion.c arithmetic, motion_fixed.hip): partials are [n_frames][tiles] uint64 SADs of
+// the Q8 blurred planes.
+hipError_t launch_motion_fixed(hipStream_t stream, int bit_depth, Elem elem, PlaneRun ref, const void* prev0,
+                               int64_t prev0_row_pitch, int n_frames, int w, int h, unsigned long long* partials);
+
 // ---- PSNR (FFmpeg psnr filter) and SSIM (FFmpeg ssim filter) ----------------------------------
 constexpr int kSseBlocksPerPlane = 256;
 // partials: [n_frames][kSseBlocksPerPlane] uint64 SSE of the (w x h) rectangle starting at a.base / b.base
@@ -104,6 +109,8 @@ struct FinalizeArgs {
   const long long* vif_fx_part[4];            // non-null: fixed-point VIF partials (kVifFxPartials int64 per tile)
   const double* adm_part[4];   int adm_tiles[4];   float adm_area[4];  // cropped-window area per scale
   const double* motion_part;   int motion_tiles;   double motion_norm;  // 2^-(bpc-8) / (w*h)
+  const unsigned long long* motion_fx_part;   // non-null: fixed-point motion SAD partials
+  unsigned motion_wh;                         // w * h, for normalize_and_scale_sad()
   const unsigned long long* sse_part[3];      // [n_frames][kSseBlocksPerPlane]: whole plane, or the right strip
   const unsigned long long* sse_part_b[3];    // nullable: bottom strip
   const unsigned long long* sse_tile_part[3]; // nullable: [n_frames][ssim_tiles] from the SSIM kernel

@@ -56,7 +56,8 @@ struct pqa_ctx {
   double* vif_part[4] = {};
   long long* vif_fx_part[4] = {};  // fixed-point VIF: int64 partials instead of (num, den) doubles
   uint16_t* vif_lut = nullptr;     // integer_vif.c's log2 table, entries 32768..65535
-  bool vif_fixed = false;
+  bool vif_fixed = false, motion_fixed = false;
+  unsigned long long* motion_fx_part = nullptr;
   int vif_tiles[4] = {};
   double* adm_part[4] = {};
   int adm_tiles[4] = {};
@@ -288,7 +289,11 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     }
     if (p0 && p0_pitch % es) return fail(c, PQA_EINVAL, "halo pitch is not a multiple of the sample size");
     ProfScope ps(c, 11, n, st_misc);
-    HIPCHK(c, launch_motion(st_misc, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h, c->inv_scale, c->motion_part));
+    if (c->motion_fixed)
+      HIPCHK(c, launch_motion_fixed(st_misc, (int)c->cfg.bit_depth, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h,
+                                    c->motion_fx_part));
+    else
+      HIPCHK(c, launch_motion(st_misc, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h, c->inv_scale, c->motion_part));
   }
   int n_sse = 0, n_ssim = 0;
   bool sse_a[3] = {false, false, false}, sse_b[3] = {false, false, false}, sse_t[3] = {false, false, false};
@@ -348,6 +353,8 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   }
   fa.motion_part = c->motion_part; fa.motion_tiles = c->motion_tiles_n;
   fa.motion_norm = (double)c->inv_scale / ((double)w * h);
+  fa.motion_fx_part = c->motion_fixed ? c->motion_fx_part : nullptr;
+  fa.motion_wh = (unsigned)w * (unsigned)h;
   for (int p = 0; p < 3; ++p) {
     fa.sse_part[p] = c->sse_part[p];
     fa.sse_use_a[p] = sse_a[p] ? 1 : 0;
@@ -482,8 +489,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   if (cfg->chroma_hshift > 2 || cfg->chroma_vshift > 2) return fail(nullptr, PQA_EINVAL, "bad chroma shift");
   if ((cfg->features & ~(uint32_t)PQA_FEAT_ALL) || cfg->features == 0)
     return fail(nullptr, PQA_EINVAL, "bad feature mask 0x%x", cfg->features);
-  if (cfg->vif_border > PQA_VIF_BORDER_INTEGER || cfg->vif_fixed > 1)
-    return fail(nullptr, PQA_EINVAL, "bad vif_border %u / vif_fixed %u", cfg->vif_border, cfg->vif_fixed);
+  if (cfg->vif_border > PQA_VIF_BORDER_INTEGER || (cfg->fixed_point & ~(uint32_t)PQA_FIXED_ALL))
+    return fail(nullptr, PQA_EINVAL, "bad vif_border %u / fixed_point 0x%x", cfg->vif_border, cfg->fixed_point);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, PQA_EDEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -540,7 +547,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   }
   CREATE_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
 
-  c->vif_fixed = (cfg->features & PQA_FEAT_VIF) && cfg->vif_fixed;
+  c->vif_fixed = (cfg->features & PQA_FEAT_VIF) && (cfg->fixed_point & PQA_FIXED_VIF);
+  c->motion_fixed = (cfg->features & PQA_FEAT_MOTION) && (cfg->fixed_point & PQA_FIXED_MOTION);
   if (c->vif_fixed) {
     std::vector<uint16_t> lut(32768);
     vif_fixed_log2_table(lut.data());
@@ -582,6 +590,7 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   c->motion_tiles_n = motion_tiles(w, h);
   if (cfg->features & PQA_FEAT_MOTION) {
     CREATE_TRY(dev_alloc(c, &c->motion_part, (size_t)c->motion_tiles_n * B));
+    if (c->motion_fixed) CREATE_TRY(dev_alloc(c, &c->motion_fx_part, (size_t)c->motion_tiles_n * B));
     c->last_luma_pitch = round_up((int64_t)w * c->esize, 64);
     CREATE_TRY(dev_alloc(c, &c->last_luma, (size_t)c->last_luma_pitch * h));
   }

@@ -18,7 +18,7 @@ class FeatureEngine:
                  chroma_shift=(1, 1), features: int = N.FEAT_VMAF, device: int = 0, max_batch: int = 0,
                  result_capacity: int = 16384, n_subsample: int = 1,
                  vif_enhn_gain_limit: float = 100.0, adm_enhn_gain_limit: float = 100.0,
-                 vif_border: int = N.VIF_BORDER_FLOAT, vif_fixed: bool = False):
+                 vif_border: int = N.VIF_BORDER_FLOAT, fixed_point: int = 0):
         self.lib = N.load()
         cfg = N.PqaConfig()
         self.lib.pqa_config_init(C.byref(cfg), width, height)
@@ -33,7 +33,7 @@ class FeatureEngine:
         cfg.vif_enhn_gain_limit = vif_enhn_gain_limit
         cfg.adm_enhn_gain_limit = adm_enhn_gain_limit
         cfg.vif_border = vif_border
-        cfg.vif_fixed = 1 if vif_fixed else 0
+        cfg.fixed_point = int(fixed_point)
         self.cfg = cfg
         self.width, self.height, self.bit_depth, self.n_planes = width, height, bit_depth, n_planes
         self.dtype = np.uint8 if bit_depth <= 8 else np.dtype("<u2")

@@ -27,10 +27,10 @@ def score_files(reference_path: str, distorted_path: str, model: str | None = "v
                 psnr: bool = True, ssim: bool = True, n_subsample: int = 1, device: int = 0,
                 rank: int = 0, world_size: int = 1, gather_device=None, max_batch: int = 0,
                 progress=None, cancelled=None, engine_factory=None, raw_kwargs=None,
-                vif_fixed: bool = False) -> ScoreResult | None:
+                fixed_point: int = 0) -> ScoreResult | None:
     """Returns the ScoreResult on rank 0 (None on other ranks).  `progress(frames_done, frames_total)`
     is called as frames are submitted; `cancelled()` is polled between frames (True -> PqaCancelled).
-    `vif_fixed`: VIF in integer_vif.c's fixed-point arithmetic instead of f32 (include/pqa_vmaf.h)."""
+    `fixed_point`: PQA_FIXED_* mask -- extractors to run in libvmaf's fixed-point arithmetic (include/pqa_vmaf.h)."""
     from .engine import FeatureEngine
     raw_kwargs = raw_kwargs or {}
     ref_rd = open_video(reference_path, **raw_kwargs)
@@ -55,7 +55,7 @@ def score_files(reference_path: str, distorted_path: str, model: str | None = "v
                chroma_shift=(ri.hshift, ri.vshift), features=feats, device=device, max_batch=max_batch,
                result_capacity=max(b - a, 16), n_subsample=n_subsample,
                vif_enhn_gain_limit=mdl.vif_enhn_gain_limit, adm_enhn_gain_limit=mdl.adm_enhn_gain_limit,
-               vif_border=mdl.vif_border, **({"vif_fixed": True} if vif_fixed else {}))
+               vif_border=mdl.vif_border, **({"fixed_point": int(fixed_point)} if fixed_point else {}))
     try:
         if a > 0:
             eng.set_motion_halo(ref_rd.frame(a - 1)[0])   # one-frame halo in front of this rank's chunk

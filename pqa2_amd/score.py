@@ -25,8 +25,8 @@ def main(argv=None) -> int:
     ap.add_argument("--ssim-log")
     ap.add_argument("--n-subsample", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--vif-fixed", action="store_true",
-                    help="VIF in integer_vif.c's fixed-point arithmetic (bit-exact integers, about half the speed)")
+    ap.add_argument("--fixed-point", type=int, default=0,
+                    help="PQA_FIXED_* mask (1 VIF, 2 motion): extractors run in libvmaf's fixed-point arithmetic")
     a = ap.parse_args(argv)
 
     from . import report
@@ -52,7 +52,7 @@ def main(argv=None) -> int:
     try:
         res = score_files(a.reference, a.distorted, a.model, psnr=bool(a.psnr_log), ssim=bool(a.ssim_log),
                           n_subsample=a.n_subsample, device=local_rank, rank=rank, world_size=world,
-                          gather_device=gather_device, max_batch=a.batch, progress=progress, vif_fixed=a.vif_fixed)
+                          gather_device=gather_device, max_batch=a.batch, progress=progress, fixed_point=a.fixed_point)
     except Exception as e:  # one line on stderr, non-zero exit: what the caller's returncode check expects
         print(f"pqa2_amd.score: error: {e}", file=sys.stderr, flush=True)
         return 1

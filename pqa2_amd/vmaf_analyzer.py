@@ -100,7 +100,7 @@ class VMAFAnalyzer(QObject):
         self.device = 0                       # HIP device ordinal for single-process runs
         self.gpus = 1                         # >1: frame-sharded child job, one process per GPU
         self.max_batch = 0                    # 0: the library sizes launches itself
-        self.vif_fixed_point = False          # True: integer_vif.c's arithmetic for VIF (exact integers, slower)
+        self.fixed_point = 0                  # PQA_FIXED_* mask (1 VIF, 2 motion): libvmaf's integer arithmetic, slower
         self.last_fps = 0.0
         self._engine_factory = None           # tests inject a stand-in; product code leaves it None
 
@@ -262,7 +262,7 @@ class VMAFAnalyzer(QObject):
             res = score_files(ref, dis, model, psnr=bool(psnr_path), ssim=bool(ssim_path),
                               n_subsample=max(1, int(self.feature_subsample or 1)), device=self.device,
                               max_batch=self.max_batch, engine_factory=self._engine_factory,
-                              vif_fixed=self.vif_fixed_point,
+                              fixed_point=self.fixed_point,
                               progress=lambda d, t: self._emit_progress(d, total_frames or t, state),
                               cancelled=lambda: self._terminate_requested)
         except N.PqaCancelled:
@@ -298,8 +298,8 @@ class VMAFAnalyzer(QObject):
                "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pqa2_amd.score",
                ref, dis, "--model", model, "--json", json_path,
                "--n-subsample", str(max(1, int(self.feature_subsample or 1))), "--batch", str(self.max_batch)]
-        if self.vif_fixed_point:
-            cmd.append("--vif-fixed")
+        if self.fixed_point:
+            cmd += ["--fixed-point", str(int(self.fixed_point))]
         if psnr_path:
             cmd += ["--psnr-log", psnr_path]
         if ssim_path:

@@ -121,8 +121,8 @@ def test_one_oracle_frame_at_1080p(oracle32):
 
 
 def test_fixed_point_vif_at_1080p_and_through_the_analyzer(tmp_path):
-    """vif_fixed at a BASELINE size: bit-equal to the fixed-point restatement on full frames (edge tiles, all four
-    scales, several launches), and reachable through VMAFAnalyzer (`vif_fixed_point`)."""
+    """fixed_point at a BASELINE size: bit-equal to the fixed-point restatement on full frames (edge tiles, all four
+    scales, several launches), and reachable through VMAFAnalyzer (`fixed_point`)."""
     from oracle.int_oracle import IntOracle
     from pqa2_amd.engine import FeatureEngine
     from pqa2_amd.vmaf_analyzer import VMAFAnalyzer
@@ -130,11 +130,13 @@ def test_fixed_point_vif_at_1080p_and_through_the_analyzer(tmp_path):
     w, h = 1920, 1080
     refs, diss = synth.make_clip(w, h, 3, 8, chroma=False)
     want = np.stack([into.vif(refs[i][0], diss[i][0]) for i in range(3)])
-    with FeatureEngine(w, h, vif_fixed=True, max_batch=2) as eng:
+    with FeatureEngine(w, h, fixed_point=3, max_batch=2) as eng:
         for i in range(3):
             eng.submit(i, refs[i], diss[i])
         got = eng.collect(0, 3)
     assert np.array_equal(got[:, :8].view(np.uint64), want.view(np.uint64))
+    blur = [into.motion_blur(refs[i][0]) for i in range(3)]
+    assert got[:, 16].tolist() == [0.0] + [into.motion_score(into.motion_sad(blur[i - 1], blur[i]), w, h) for i in (1, 2)]
     # analyzer: same files scored in both arithmetic modes differ by the quantisation residual only
     rp, dp, r2, d2 = _pair(tmp_path, 352, 288, 4, 8)
     scores = {}
@@ -142,7 +144,7 @@ def test_fixed_point_vif_at_1080p_and_through_the_analyzer(tmp_path):
         a = VMAFAnalyzer()
         a.set_output_directory(str(tmp_path))
         a.set_test_name("fx" if fixed else "fl")
-        a.vif_fixed_point = fixed
+        a.fixed_point = 3 if fixed else 0
         res = a.analyze_videos(rp, dp, "vmaf_v0.6.1")
         assert res is not None
         scores[fixed] = res
