@@ -14,7 +14,7 @@ FEAT_VIF, FEAT_ADM, FEAT_MOTION, FEAT_PSNR, FEAT_SSIM = 1, 2, 4, 8, 16
 FEAT_VMAF = FEAT_VIF | FEAT_ADM | FEAT_MOTION
 FEAT_ALL = FEAT_VMAF | FEAT_PSNR | FEAT_SSIM
 VIF_BORDER_FLOAT, VIF_BORDER_INTEGER = 0, 1  # pqa_config.vif_border (include/pqa_vmaf.h)
-FIXED_VIF, FIXED_MOTION, FIXED_ALL = 1, 2, 3   # pqa_config.fixed_point mask
+FIXED_VIF, FIXED_MOTION, FIXED_ADM, FIXED_ALL = 1, 2, 4, 7   # pqa_config.fixed_point mask
 REC_VIF_NUM, REC_VIF_DEN, REC_ADM_NUM, REC_ADM_DEN, REC_MOTION, REC_SSIM, REC_SSE = 0, 4, 8, 12, 16, 17, 20
 RECORD_DOUBLES = 24
 PROF_KERNELS = 15

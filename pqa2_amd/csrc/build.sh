@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 OBJS=()
-for f in vif vif_fixed adm motion motion_fixed psnr_ssim luma_stats finalize pqa_api; do
+for f in vif vif_fixed adm adm_fixed motion motion_fixed psnr_ssim luma_stats finalize pqa_api; do
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ kernels.h -nt "$f.o" ] || [ pqa_device.h -nt "$f.o" ] || [ ../../include/pqa_vmaf.h -nt "$f.o" ]; then
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
   fi

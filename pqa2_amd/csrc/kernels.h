@@ -60,6 +60,27 @@ hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun r
                             int w, int h, float inv_scale, float gain_limit, MutPlaneRun ll_ref,
                             MutPlaneRun ll_dis, double* partials);
 
+// Fixed-point ADM (integer_adm.c arithmetic, adm_fixed.hip).  Same tiling as launch_adm_scale; the approximation
+// bands handed to the next scale are int32 planes (4-byte elements: pass them on as ELEM_F32-sized runs).
+// partials: [n_frames][tiles][kAdmFxRows][6] int64 per-row sums {num h,v,d, den h,v,d} (row 0 and 15 = halo, zero).
+constexpr int kAdmFxRows = kAdmTileH + 2;
+struct AdmFxScale {           // per-scale constants of the fixed-point path, shared by kernel, finalize and host epilogue
+  int scale, band_w, band_h;
+  int left, top, right, bottom;
+  float rf[3];
+  uint32_t i_rf[3];
+  int cm_shift_sq[3], cm_shift_sub[3], cm_shift_cub[3], cm_final_q[3];
+  int den_shift_sq, den_shift_cub, den_final_q;
+  int num_row_shift, den_row_shift;
+};
+AdmFxScale adm_fixed_scale_params(int scale, int band_w, int band_h);
+void adm_fixed_div_table(int32_t* out65537);  // host: div_lookup of integer_adm.c (2^30 / i, odd-symmetric)
+// host: {num_scale, den_scale} from the six integer accumulators, as adm_cm / adm_csf_den_scale finish them
+void adm_fixed_epilogue(const AdmFxScale& p, const long long acc[6], double* num_out, double* den_out);
+hipError_t launch_adm_fixed(hipStream_t stream, int scale, int bit_depth, Elem elem, PlaneRun ref, PlaneRun dis,
+                            int n_frames, int w, int h, double gain_limit, const int32_t* div_lut,
+                            MutPlaneRun ll_ref, MutPlaneRun ll_dis, long long* partials);
+
 // ---- motion ---------------------------------------------------------------------------------
 constexpr int kMotionTileW = 252, kMotionTileH = 16;
 inline int motion_tiles(int w, int h) {
@@ -108,6 +129,9 @@ struct FinalizeArgs {
   const double* vif_part[4];   int vif_tiles[4];
   const long long* vif_fx_part[4];            // non-null: fixed-point VIF partials (kVifFxPartials int64 per tile)
   const double* adm_part[4];   int adm_tiles[4];   float adm_area[4];  // cropped-window area per scale
+  const long long* adm_fx_part[4];            // non-null: fixed-point ADM per-row partials
+  int adm_fx_tiles_x[4], adm_fx_top[4], adm_fx_bottom[4], adm_fx_num_shift[4], adm_fx_den_shift[4];
+  long long* adm_fx_acc;                      // [capacity][4][6] ring: the six accumulators per frame and scale
   const double* motion_part;   int motion_tiles;   double motion_norm;  // 2^-(bpc-8) / (w*h)
   const unsigned long long* motion_fx_part;   // non-null: fixed-point motion SAD partials
   unsigned motion_wh;                         // w * h, for normalize_and_scale_sad()

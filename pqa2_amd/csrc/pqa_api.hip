@@ -56,7 +56,11 @@ struct pqa_ctx {
   double* vif_part[4] = {};
   long long* vif_fx_part[4] = {};  // fixed-point VIF: int64 partials instead of (num, den) doubles
   uint16_t* vif_lut = nullptr;     // integer_vif.c's log2 table, entries 32768..65535
-  bool vif_fixed = false, motion_fixed = false;
+  bool vif_fixed = false, motion_fixed = false, adm_fixed = false;
+  long long* adm_fx_part[4] = {};   // fixed-point ADM: per-row int64 partials
+  long long* adm_fx_acc = nullptr;  // [capacity][4][6] ring of accumulators, finished on the host in pqa_collect
+  int32_t* adm_div_lut = nullptr;
+  AdmFxScale adm_fx[4] = {};
   unsigned long long* motion_fx_part = nullptr;
   int vif_tiles[4] = {};
   double* adm_part[4] = {};
@@ -255,7 +259,31 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       }
     }
   }
-  if ((feat & PQA_FEAT_ADM) && sp_n > 0) {
+  if ((feat & PQA_FEAT_ADM) && sp_n > 0 && c->adm_fixed) {
+    PlaneRun cr = rYs, cd = dYs;
+    Elem ce = c->elem;
+    int cw = w, ch = h;
+    for (int s = 0; s < 4; ++s) {
+      MutPlaneRun lr{nullptr, 0, 0}, ld{nullptr, 0, 0};
+      if (s < 3) {  // the approximation-band buffers hold int32 planes in this mode (same 4-byte elements)
+        Level& L = c->adm_lv[s + 1];
+        lr = MutPlaneRun{L.ref, L.pitch, L.frame_pitch};
+        ld = MutPlaneRun{L.dis, L.pitch, L.frame_pitch};
+      }
+      {
+        ProfScope ps(c, 7 + s, sp_n, st_adm);
+        HIPCHK(c, launch_adm_fixed(st_adm, s, (int)c->cfg.bit_depth, ce, cr, cd, sp_n, cw, ch,
+                                   c->cfg.adm_enhn_gain_limit, c->adm_div_lut, lr, ld, c->adm_fx_part[s]));
+      }
+      if (s < 3) {
+        Level& L = c->adm_lv[s + 1];
+        cr = PlaneRun{L.ref, L.pitch, L.frame_pitch};
+        cd = PlaneRun{L.dis, L.pitch, L.frame_pitch};
+        ce = ELEM_F32;
+        cw = L.w; ch = L.h;
+      }
+    }
+  } else if ((feat & PQA_FEAT_ADM) && sp_n > 0) {
     PlaneRun cr = rYs, cd = dYs;
     Elem ce = c->elem;
     int cw = w, ch = h;
@@ -350,6 +378,10 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     fa.vif_part[s] = c->vif_part[s]; fa.vif_tiles[s] = c->vif_tiles[s];
     fa.vif_fx_part[s] = c->vif_fixed ? c->vif_fx_part[s] : nullptr;
     fa.adm_part[s] = c->adm_part[s]; fa.adm_tiles[s] = c->adm_tiles[s]; fa.adm_area[s] = c->adm_area[s];
+    fa.adm_fx_part[s] = c->adm_fixed ? c->adm_fx_part[s] : nullptr;
+    fa.adm_fx_tiles_x[s] = adm_tiles_x(c->adm_fx[s].band_w);
+    fa.adm_fx_top[s] = c->adm_fx[s].top; fa.adm_fx_bottom[s] = c->adm_fx[s].bottom;
+    fa.adm_fx_num_shift[s] = c->adm_fx[s].num_row_shift; fa.adm_fx_den_shift[s] = c->adm_fx[s].den_row_shift;
   }
   fa.motion_part = c->motion_part; fa.motion_tiles = c->motion_tiles_n;
   fa.motion_norm = (double)c->inv_scale / ((double)w * h);
@@ -362,6 +394,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     fa.sse_tile_part[p] = sse_t[p] ? c->sse_tile_part[p] : nullptr;
     fa.ssim_part[p] = c->ssim_part[p]; fa.ssim_tiles[p] = c->ssim_tiles_n[p]; fa.ssim_norm[p] = c->ssim_norm[p];
   }
+  fa.adm_fx_acc = c->adm_fx_acc;
   fa.records = c->records;
   fa.record_stride = PQA_RECORD_DOUBLES;
   fa.capacity = c->capacity;
@@ -549,6 +582,13 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
 
   c->vif_fixed = (cfg->features & PQA_FEAT_VIF) && (cfg->fixed_point & PQA_FIXED_VIF);
   c->motion_fixed = (cfg->features & PQA_FEAT_MOTION) && (cfg->fixed_point & PQA_FIXED_MOTION);
+  c->adm_fixed = (cfg->features & PQA_FEAT_ADM) && (cfg->fixed_point & PQA_FIXED_ADM);
+  if (c->adm_fixed) {
+    std::vector<int32_t> lut(65537);
+    adm_fixed_div_table(lut.data());
+    CREATE_TRY(dev_alloc(c, &c->adm_div_lut, lut.size()));
+    CREATE_HIP(hipMemcpy(c->adm_div_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   if (c->vif_fixed) {
     std::vector<uint16_t> lut(32768);
     vif_fixed_log2_table(lut.data());
@@ -585,7 +625,11 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
       CREATE_TRY(dev_alloc(c, &c->vif_part[s], (size_t)c->vif_tiles[s] * 2 * B));
     if ((cfg->features & PQA_FEAT_VIF) && c->vif_fixed)
       CREATE_TRY(dev_alloc(c, &c->vif_fx_part[s], (size_t)c->vif_tiles[s] * kVifFxPartials * B));
-    if (cfg->features & PQA_FEAT_ADM) CREATE_TRY(dev_alloc(c, &c->adm_part[s], (size_t)c->adm_tiles[s] * 6 * B));
+    c->adm_fx[s] = adm_fixed_scale_params(s, bw, bh);
+    if ((cfg->features & PQA_FEAT_ADM) && !c->adm_fixed)
+      CREATE_TRY(dev_alloc(c, &c->adm_part[s], (size_t)c->adm_tiles[s] * 6 * B));
+    if ((cfg->features & PQA_FEAT_ADM) && c->adm_fixed)
+      CREATE_TRY(dev_alloc(c, &c->adm_fx_part[s], (size_t)c->adm_tiles[s] * kAdmFxRows * 6 * B));
   }
   c->motion_tiles_n = motion_tiles(w, h);
   if (cfg->features & PQA_FEAT_MOTION) {
@@ -609,6 +653,10 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   }
   CREATE_TRY(dev_alloc(c, &c->luma_part, (size_t)kLumaBlocks * 3 * B));
   CREATE_TRY(dev_alloc(c, &c->luma_out, (size_t)3 * B));
+  if (c->adm_fixed) {
+    CREATE_TRY(dev_alloc(c, &c->adm_fx_acc, (size_t)c->capacity * 24));
+    CREATE_HIP(hipMemsetAsync(c->adm_fx_acc, 0, (size_t)c->capacity * 24 * sizeof(long long), c->stream));
+  }
   CREATE_TRY(dev_alloc(c, &c->records, (size_t)c->capacity * PQA_RECORD_DOUBLES));
   CREATE_HIP(hipMemsetAsync(c->records, 0, (size_t)c->capacity * PQA_RECORD_DOUBLES * sizeof(double), c->stream));
   CREATE_HIP(hipStreamSynchronize(c->stream));
@@ -795,6 +843,23 @@ int pqa_collect(pqa_ctx* c, int64_t first_index, int32_t count, double* records)
     const int n = (int)((c->capacity - row) < (count - done) ? (c->capacity - row) : (count - done));
     HIPCHK(c, hipMemcpy(records + (size_t)done * PQA_RECORD_DOUBLES, c->records + (size_t)row * PQA_RECORD_DOUBLES,
                         n * rec_bytes, hipMemcpyDeviceToHost));
+    if (c->adm_fixed) {
+      // integer_adm.c's scalar epilogue (six cube roots per scale) on the host, with the libm libvmaf would use:
+      // the integer accumulators are exact, so are the resulting adm num / den
+      std::vector<long long> acc;
+      try {
+        acc.resize((size_t)n * 24);
+      } catch (...) {
+        return fail(c, PQA_ENOMEM, "out of host memory");
+      }
+      HIPCHK(c, hipMemcpy(acc.data(), c->adm_fx_acc + (size_t)row * 24, acc.size() * sizeof(long long),
+                          hipMemcpyDeviceToHost));
+      for (int f = 0; f < n; ++f)
+        for (int s = 0; s < 4; ++s) {
+          double* rec = records + (size_t)(done + f) * PQA_RECORD_DOUBLES;
+          adm_fixed_epilogue(c->adm_fx[s], &acc[(size_t)f * 24 + s * 6], &rec[PQA_REC_ADM_NUM + s], &rec[PQA_REC_ADM_DEN + s]);
+        }
+    }
     done += n;
     row = 0;
   }

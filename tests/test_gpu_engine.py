@@ -130,11 +130,13 @@ def test_fixed_point_vif_at_1080p_and_through_the_analyzer(tmp_path):
     w, h = 1920, 1080
     refs, diss = synth.make_clip(w, h, 3, 8, chroma=False)
     want = np.stack([into.vif(refs[i][0], diss[i][0]) for i in range(3)])
-    with FeatureEngine(w, h, fixed_point=3, max_batch=2) as eng:
+    with FeatureEngine(w, h, fixed_point=7, max_batch=2) as eng:
         for i in range(3):
             eng.submit(i, refs[i], diss[i])
         got = eng.collect(0, 3)
     assert np.array_equal(got[:, :8].view(np.uint64), want.view(np.uint64))
+    want_adm = np.stack([into.adm(refs[i][0], diss[i][0]) for i in range(3)])
+    assert np.array_equal(got[:, 8:16].view(np.uint64), want_adm.view(np.uint64))
     blur = [into.motion_blur(refs[i][0]) for i in range(3)]
     assert got[:, 16].tolist() == [0.0] + [into.motion_score(into.motion_sad(blur[i - 1], blur[i]), w, h) for i in (1, 2)]
     # analyzer: same files scored in both arithmetic modes differ by the quantisation residual only
@@ -144,7 +146,7 @@ def test_fixed_point_vif_at_1080p_and_through_the_analyzer(tmp_path):
         a = VMAFAnalyzer()
         a.set_output_directory(str(tmp_path))
         a.set_test_name("fx" if fixed else "fl")
-        a.fixed_point = 3 if fixed else 0
+        a.fixed_point = 7 if fixed else 0
         res = a.analyze_videos(rp, dp, "vmaf_v0.6.1")
         assert res is not None
         scores[fixed] = res

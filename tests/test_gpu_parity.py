@@ -70,27 +70,27 @@ def test_vif_integer_border(oracle64, w, h, bpc):
 
 @pytest.mark.parametrize("w,h,bpc,gain", [(64, 48, 8, 100.0), (321, 241, 8, 100.0), (130, 18, 8, 100.0), (16, 16, 8, 100.0),
                                           (640, 362, 8, 1.0), (200, 120, 10, 100.0), (96, 80, 12, 1.0)])
-def test_vif_fixed_point_is_bit_exact(oracle64, w, h, bpc, gain):
-    """pqa_config.fixed_point: integer_vif.c's and integer_motion.c's arithmetic in HIP (csrc/vif_fixed.hip,
-    motion_fixed.hip).  Integer work, so the bar is bit-equality of the eight VIF doubles and of motion with the
-    fixed-point restatement (oracle/vmaf_int_oracle.c); ADM stays on the f32 kernel."""
+def test_fixed_point_is_bit_exact(w, h, bpc, gain):
+    """pqa_config.fixed_point: integer_vif.c's, integer_adm.c's and integer_motion.c's arithmetic in HIP
+    (csrc/vif_fixed.hip, adm_fixed.hip, motion_fixed.hip).  Integer work, so the bar is bit-equality of all 17
+    feature doubles with the fixed-point restatement (oracle/vmaf_int_oracle.c)."""
     from oracle.int_oracle import IntOracle
     from pqa2_amd import _native as N
     into = IntOracle()
     n = 3
     refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
     want = np.stack([into.vif(refs[i][0], diss[i][0], bpc, gain) for i in range(n)])
+    want_adm = np.stack([into.adm(refs[i][0], diss[i][0], bpc, gain) for i in range(n)])
     blur = [into.motion_blur(refs[i][0], bpc) for i in range(n)]
     want_motion = [0.0] + [into.motion_score(into.motion_sad(blur[i - 1], blur[i]), w, h) for i in range(1, n)]
-    exp = _oracle_clip(oracle64, refs, diss, bpc)
-    with _engine(w, h, bit_depth=bpc, fixed_point=N.FIXED_ALL, vif_enhn_gain_limit=gain, max_batch=2) as eng:
+    with _engine(w, h, bit_depth=bpc, fixed_point=N.FIXED_ALL, vif_enhn_gain_limit=gain, adm_enhn_gain_limit=gain,
+                 max_batch=2) as eng:
         for i in range(n):
             eng.submit(i, refs[i], diss[i])
         got = eng.collect(0, n)[:, :17]
     assert np.array_equal(got[:, :8].view(np.uint64), want.view(np.uint64)), np.abs(got[:, :8] - want).max()
     assert got[:, 16].tolist() == want_motion
-    rel = np.abs(got[:, 8:16] - exp[:, 8:16]) / np.maximum(np.abs(exp[:, 8:16]), 1e-12)
-    assert rel.max() < REL_TOL
+    assert np.array_equal(got[:, 8:16].view(np.uint64), want_adm.view(np.uint64)), np.abs(got[:, 8:16] - want_adm).max()
 
 
 @pytest.mark.parametrize("bpc", [10, 12])
