@@ -59,28 +59,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) 
     }
   }
   if (a.has_adm && grp >= 4 && grp < 8 && a.adm_fx_part[grp - 4]) {
-    // integer_adm.c: a row's sum is complete only across the tiles of that row; then the per-row shift, then rows
-    const int s = grp - 4;
-    const long long* p = a.adm_fx_part[s] + (int64_t)fr * a.adm_tiles[s] * (kAdmFxRows * 6);
-    const int tiles_x = a.adm_fx_tiles_x[s];
-    for (int q = 0; q < 6; ++q) {
-      const int shift = q < 3 ? a.adm_fx_num_shift[s] : a.adm_fx_den_shift[s];
-      const unsigned long long add = shift > 0 ? 1ull << (shift - 1) : 0ull;
-      unsigned long long v = 0;
-      for (int r = a.adm_fx_top[s] + tid; r < a.adm_fx_bottom[s]; r += kBlock) {
-        const int ty = r / kAdmTileH, lr = r - ty * kAdmTileH + 1;
-        unsigned long long rowsum = 0;
-        for (int tx = 0; tx < tiles_x; ++tx)
-          rowsum += (unsigned long long)p[((int64_t)(ty * tiles_x + tx) * kAdmFxRows + lr) * 6 + q];
-        v += (rowsum + add) >> shift;
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      __syncthreads();
-      if ((tid & 63) == 0) redu[tid >> 6] = v;
-      __syncthreads();
-      if (tid == 0) a.adm_fx_acc[((int64_t)row * 4 + s) * 6 + q] = (long long)((redu[0] + redu[1]) + (redu[2] + redu[3]));
-    }
+    // fixed-point ADM is finished by adm_fixed_finalize_kernel (24 workgroups per frame instead of 4)
   } else if (a.has_adm && grp >= 4 && grp < 8) {
     {
       const int s = grp - 4;
@@ -138,11 +117,39 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const FinalizeArgs a) 
   }
 }
 
+// integer_adm.c: a row's sum is complete only across the tiles of that row; then the per-row shift, then the rows.
+// One workgroup per (frame, scale, quantity); a thread owns whole rows, so the order of the exact integer adds is free.
+__global__ __launch_bounds__(kBlock) void adm_fixed_finalize_kernel(const FinalizeArgs a) {
+  __shared__ unsigned long long redu[4];
+  const int fr = blockIdx.x, s = blockIdx.y / 6, q = blockIdx.y % 6, tid = threadIdx.x;
+  if (!a.adm_fx_part[s]) return;
+  const int row = (int)(((int64_t)a.slot_base + (int64_t)fr * a.slot_step) % a.capacity);
+  const long long* p = a.adm_fx_part[s] + (int64_t)fr * a.adm_tiles[s] * (kAdmFxRows * 6);
+  const int tiles_x = a.adm_fx_tiles_x[s];
+  const int shift = q < 3 ? a.adm_fx_num_shift[s] : a.adm_fx_den_shift[s];
+  const unsigned long long add = shift > 0 ? 1ull << (shift - 1) : 0ull;
+  unsigned long long v = 0;
+  for (int r = a.adm_fx_top[s] + tid; r < a.adm_fx_bottom[s]; r += kBlock) {
+    const int ty = r / kAdmTileH, lr = r - ty * kAdmTileH + 1;
+    unsigned long long rowsum = 0;
+    for (int tx = 0; tx < tiles_x; ++tx)
+      rowsum += (unsigned long long)p[((int64_t)(ty * tiles_x + tx) * kAdmFxRows + lr) * 6 + q];
+    v += (rowsum + add) >> shift;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((tid & 63) == 0) redu[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) a.adm_fx_acc[((int64_t)row * 4 + s) * 6 + q] = (long long)((redu[0] + redu[1]) + (redu[2] + redu[3]));
+}
+
 }  // namespace
 
 hipError_t launch_finalize(hipStream_t stream, const FinalizeArgs& args) {
   if (args.n_frames <= 0) return hipSuccess;
   hipLaunchKernelGGL(finalize_kernel, dim3(args.n_frames, 9), dim3(kBlock), 0, stream, args);
+  if (args.has_adm && args.adm_fx_part[0])
+    hipLaunchKernelGGL(adm_fixed_finalize_kernel, dim3(args.n_frames, 24), dim3(kBlock), 0, stream, args);
   return hipGetLastError();
 }
 
