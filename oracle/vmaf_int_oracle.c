@@ -16,8 +16,9 @@
  * with the float restatement to the quantisation level expected of each Q format
  * (tests/test_int_oracle.py), and closed forms (static clip -> motion 0; identical frames).
  *
- * Purpose in this round: quantify how far the float extractors (what the HIP kernels compute) sit
- * from the fixed-point ones the default model names -- see DESIGN.md "float vs fixed-point".
+ * Uses: (i) quantify how far the float extractors (the default HIP path) sit from the fixed-point ones
+ * the default model names -- DESIGN.md section 1b; (ii) the checker for the opt-in fixed-point HIP kernels
+ * (pqa2_amd/csrc/{vif,adm,motion}_fixed.hip), which must equal it bit for bit (tests/test_gpu_parity.py).
  * Nothing in pqa2_amd/ loads this file's shared object.
  */
 #include <math.h>

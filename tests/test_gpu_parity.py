@@ -368,3 +368,43 @@ def test_random_geometry_sweep(oracle64, oracle32):
         for p in range(3):
             assert int(sse[1, p]) == oracle32.sse_plane(diss[1][p], refs[1][p], 8)
             assert abs(rec[1, 17 + p] - oracle32.ssim_plane(diss[1][p], refs[1][p], 8)) < 1e-9
+
+
+def test_fixed_point_random_geometry_sweep():
+    """The fixed-point kernels over odd / tiny / non-tile-multiple geometries and hard content (noise, flat
+    patches with exact zeros, ramps, saturated extremes): every feature double bit-equal to the restatement."""
+    from oracle.int_oracle import IntOracle
+    from pqa2_amd import _native as N
+    into = IntOracle()
+    rng = np.random.default_rng(20250419)
+    sizes = [(16, 16), (17, 31), (61, 29), (63, 63), (121, 31), (239, 17), (241, 33), (253, 40), (130, 57), (484, 30),
+             (rng.integers(16, 300), rng.integers(16, 120)), (rng.integers(16, 300), rng.integers(16, 120))]
+    for n_case, (w, h) in enumerate(sizes):
+        w, h = int(w), int(h)
+        kind = n_case % 4
+        bpc = 10 if n_case % 5 == 4 else 8
+        peak = (1 << bpc) - 1
+        frames = []
+        for t in range(2):
+            if kind == 0:
+                y = rng.integers(0, peak + 1, (h, w))
+            elif kind == 1:
+                y = np.repeat(np.repeat(rng.integers(0, peak + 1, (-(-h // 16), -(-w // 16))), 16, 0), 16, 1)[:h, :w] + t
+            elif kind == 2:
+                y = (np.add.outer(np.arange(h) * 2, np.arange(w)) + 7 * t) % (peak + 1)
+            else:             # extremes: checkerboard of 0 / peak, the largest coefficients the Q formats must hold
+                y = ((np.add.outer(np.arange(h), np.arange(w)) + t) % 2) * peak
+            frames.append(np.clip(y, 0, peak).astype(np.uint8 if bpc == 8 else np.uint16))
+        dis = [np.clip(f.astype(np.int32) + rng.integers(-6, 7, f.shape), 0, peak).astype(f.dtype) for f in frames]
+        want = np.zeros((2, 17))
+        for i in range(2):
+            want[i, 0:8] = into.vif(frames[i], dis[i], bpc)
+            want[i, 8:16] = into.adm(frames[i], dis[i], bpc)
+        b0, b1 = into.motion_blur(frames[0], bpc), into.motion_blur(frames[1], bpc)
+        want[1, 16] = into.motion_score(into.motion_sad(b0, b1), w, h)
+        with _engine(w, h, bit_depth=bpc, fixed_point=N.FIXED_ALL, max_batch=2) as eng:
+            for i in range(2):
+                eng.submit(i, [frames[i]], [dis[i]])
+            got = eng.collect(0, 2)[:, :17]
+        bad = np.argwhere(got.view(np.uint64) != want.view(np.uint64))
+        assert bad.size == 0, (w, h, kind, bpc, bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
