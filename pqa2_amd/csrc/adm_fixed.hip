@@ -93,10 +93,27 @@ __device__ __forceinline__ int gain_limit_rst(int rst, int t, double gl) {
   return rst;
 }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
+// Wave sums of 24 int64 values per lane (6 quantities x this wave's 4 band rows) as a reduce-scatter: at lane
+// distance 32, 16, 8 every lane hands the half of its values it does not keep to its partner, so the number of live
+// values halves each step (12 + 6 + 3 exchanges instead of 24 per step); the last three distances reduce 3 values.
+// Afterwards lane L holds, in v[0..2], the wave totals of original indices 12*b5 + 6*b4 + 3*b3 + {0,1,2}
+// (b5, b4, b3 = bits 5, 4, 3 of L).  Exact integer adds: the order is free.
+__device__ __forceinline__ void wave_reduce_scatter24(long long (&v)[24], int lane) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  for (int step = 0; step < 3; ++step) {
+    const int m = 32 >> step, n = 12 >> step;
+    const bool up = (lane & m) != 0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const long long send = up ? v[i] : v[i + n];
+      const long long keep = up ? v[i + n] : v[i];
+      v[i] = keep + __shfl_xor(send, m, 64);
+    }
+  }
+#pragma unroll
+  for (int m = 4; m > 0; m >>= 1)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] += __shfl_xor(v[i], m, 64);
 }
 
 template <typename T, bool WIDE>
@@ -233,7 +250,8 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int kq = decouple_k<WIDE>(o3[t], t3[t], a.div_lut);
-      int rst = (int)(((long long)kq * o3[t] + 16384) >> 15);
+      // k <= 2^15; at scale 0 |o| <= 2^15 as well, so k * o fits 32 bits there
+      int rst = WIDE ? (int)(((long long)kq * o3[t] + 16384) >> 15) : (kq * o3[t] + 16384) >> 15;
       if (angle) rst = gain_limit_rst(rst, t3[t], a.gain_limit);
       rs[k][t] = rst;
       const int add = t3[t] - rst;
@@ -259,8 +277,9 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
       unsigned long long val = 0;
       if (win[k]) {
         const unsigned long long v = (unsigned long long)iabs64(o3[t]);
-        if (!WIDE) {
-          val = v * v * v;
+        if (!WIDE) {  // |o| <= 2^15: the square fits 32 bits, the cube is one 32 x 32 -> 64 multiply
+          const unsigned v32 = (unsigned)v;
+          val = (unsigned long long)(v32 * v32) * v32;
         } else {
           const unsigned long long sq = (v * v + (1ull << (a.den_shift_sq - 1))) >> a.den_shift_sq;
           const unsigned long long add_cub = a.den_shift_cub > 0 ? 1ull << (a.den_shift_cub - 1) : 0ull;
@@ -276,6 +295,7 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
   const int lx0 = have ? min(max(mirror1(cx - 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
   const int lx2 = have ? min(max(mirror1(cx + 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
   long long* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * (GH * 6);
+  long long sums[24];  // index k * 6 + {num h,v,d, den h,v,d}
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int lr = wave + 4 * k;
@@ -289,25 +309,40 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
                       F[ly2][lcxs] + F[ly2][lx2] + centre[k];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        long long x;
-        if (!WIDE) x = (long long)(rs[k][t] * (int)a.i_rf[t]);
-        else x = ((long long)a.i_rf[t] * rs[k][t] + (1ll << 27)) >> 28;
-        x = iabs64(x) - (thr << a.cm_shift_sub[t]);
-        if (x < 0) x = 0;
-        const long long x_sq = (x * x + (1ll << (a.cm_shift_sq[t] - 1))) >> a.cm_shift_sq[t];
         const long long add_cub = a.cm_shift_cub[t] > 0 ? 1ll << (a.cm_shift_cub[t] - 1) : 0ll;
-        num[t] = (x_sq * x + add_cub) >> a.cm_shift_cub[t];
+        if (!WIDE) {
+          // |r * w| < 2^31, so after the threshold x is a 32-bit quantity: x^2 is one 32 x 32 -> 64 multiply, and
+          // x_sq (< 2^34) * x splits into two of them (same integers as the 64-bit forms of the C code)
+          const int xw = rs[k][t] * (int)a.i_rf[t];
+          const long long xs = (long long)(unsigned)(xw < 0 ? -xw : xw) - (thr << a.cm_shift_sub[t]);
+          const unsigned x = xs < 0 ? 0u : (unsigned)xs;
+          const unsigned long long x_sq = ((unsigned long long)x * x + (1ull << (a.cm_shift_sq[t] - 1))) >> a.cm_shift_sq[t];
+          const unsigned long long cub = (unsigned long long)(unsigned)x_sq * x +
+                                         ((unsigned long long)((unsigned)(x_sq >> 32) * x) << 32);
+          num[t] = (long long)((cub + (unsigned long long)add_cub) >> a.cm_shift_cub[t]);
+        } else {
+          long long x = ((long long)a.i_rf[t] * rs[k][t] + (1ll << 27)) >> 28;
+          x = iabs64(x) - (thr << a.cm_shift_sub[t]);
+          if (x < 0) x = 0;
+          const long long x_sq = (x * x + (1ll << (a.cm_shift_sq[t] - 1))) >> a.cm_shift_sq[t];
+          num[t] = (x_sq * x + add_cub) >> a.cm_shift_cub[t];
+        }
       }
     }
-    // all lanes of a wave hold coefficients of the same band row: one exact integer sum per row and quantity
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      const long long n = wave_sum_i64(num[t]);
-      const long long dsum = wave_sum_i64(den[k][t]);
-      if (lcx == 0) {
-        out[lr * 6 + t] = n;
-        out[lr * 6 + 3 + t] = dsum;
-      }
+      sums[k * 6 + t] = num[t];
+      sums[k * 6 + 3 + t] = den[k][t];
+    }
+  }
+  // all lanes of a wave hold coefficients of the same four band rows: one exact integer sum per row and quantity
+  wave_reduce_scatter24(sums, lcx);
+  if ((lcx & 7) == 0) {
+    const int base = 12 * ((lcx >> 5) & 1) + 6 * ((lcx >> 4) & 1) + 3 * ((lcx >> 3) & 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = base + j, k = idx / 6, q = idx - 6 * k;
+      out[(wave + 4 * k) * 6 + q] = sums[j];
     }
   }
 }
