@@ -211,6 +211,19 @@ def test_n_subsample_and_cancel():
         sub = eng.collect(0, n)
     assert np.array_equal(sub[::2, :16], full[::2, :16])      # spatial features on frames 0, 2, 4
     assert np.array_equal(sub[:, 16], full[:, 16])            # motion on every frame
+    # the fixed-point mode goes through the same slot mapping (its own finalize kernels) and a wrapping record ring
+    with _engine(w, h, fixed_point=N.FIXED_ALL) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        fx_full = eng.collect(0, n)
+    with _engine(w, h, fixed_point=N.FIXED_ALL, n_subsample=2, max_batch=3, result_capacity=4) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+            if i == 2:
+                first = eng.collect(0, 3)
+        fx_sub = np.concatenate([first, eng.collect(3, 2)])
+    assert np.array_equal(fx_sub[::2, :16], fx_full[::2, :16]) and np.array_equal(fx_sub[:, 16], fx_full[:, 16])
+    assert not np.array_equal(fx_full[:, :16], full[:, :16])
     with _engine(w, h) as eng:
         eng.submit(0, refs[0], diss[0])
         eng.cancel()
