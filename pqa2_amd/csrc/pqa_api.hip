@@ -3,10 +3,13 @@
 #include "../../include/pqa_vmaf.h"
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -36,6 +39,77 @@ struct Half {
 struct ProfEv {
   hipEvent_t a, b;
   int id, frames;
+};
+
+// pqa_submit packs the caller's planes into pinned staging.  One core's memcpy (~10 GB/s) is far below PCIe, so the
+// rows of a frame pair are split into ~1 MiB tasks that a few persistent helper threads and the caller drain together.
+struct PackTask {
+  uint8_t* dst;
+  const uint8_t* src;
+  int64_t dst_pitch, src_pitch;
+  size_t row_bytes;
+  int rows;
+};
+
+class PackPool {
+ public:
+  explicit PackPool(int helpers) {
+    for (int i = 0; i < helpers; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~PackPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  void run(const PackTask* tasks, int n) {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      tasks_ = tasks; n_ = n; next_.store(0); finished_ = 0; ++gen_;
+    }
+    cv_work_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> g(m_);
+    cv_done_.wait(g, [this] { return finished_ == (int)workers_.size(); });
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_) break;
+      const PackTask& t = tasks_[i];
+      if (t.dst_pitch == t.src_pitch) {
+        memcpy(t.dst, t.src, (size_t)t.dst_pitch * (t.rows - 1) + t.row_bytes);
+      } else {
+        for (int y = 0; y < t.rows; ++y) memcpy(t.dst + (int64_t)y * t.dst_pitch, t.src + (int64_t)y * t.src_pitch, t.row_bytes);
+      }
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_work_.wait(g, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      drain();
+      std::lock_guard<std::mutex> g(m_);
+      if (++finished_ == (int)workers_.size()) cv_done_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_work_, cv_done_;
+  const PackTask* tasks_ = nullptr;
+  int n_ = 0, finished_ = 0;
+  std::atomic<int> next_{0};
+  uint64_t gen_ = 0;
+  bool stop_ = false;
 };
 
 }  // namespace
@@ -90,6 +164,9 @@ struct pqa_ctx {
   size_t plane_off[2][3] = {};
   int64_t slot_row_pitch[3] = {};
   bool staging_ready = false;
+  std::unique_ptr<PackPool> pack_pool;
+  bool pack_pool_tried = false;
+  std::vector<PackTask> pack_tasks;
   std::atomic<int> cancelled{0};
   std::string err;
   std::vector<void*> allocs;
@@ -766,24 +843,49 @@ int pqa_submit(pqa_ctx* c, int64_t frame_index, const void* const ref_planes[3],
     if ((size_t)ref_strides[p] < row_bytes || (size_t)dis_strides[p] < row_bytes)
       return fail(c, PQA_EINVAL, "plane %d stride smaller than a row", p);
   }
-  // pack into the pinned slot: the reference clip on a helper thread, the distorted clip on this one
-  // (a 2160p 4:2:0 pair is 25 MB; one core's memcpy, not PCIe, is what bounds this path otherwise)
+  // pack into the pinned slot (a 2160p 4:2:0 pair is 25 MB: one core's memcpy, not PCIe, would bound this path)
   const auto pack = [&](int side, const void* const planes[3], const int64_t strides[3]) {
     for (int p = 0; p < c->n_planes; ++p)
       copy_plane_rows(slot + c->plane_off[side][p], c->slot_row_pitch[p], (const uint8_t*)planes[p], strides[p],
                       (size_t)c->pw[p] * c->esize, c->ph[p]);
   };
-  bool split = c->slot_bytes >= (4u << 20);
-  if (split) {
-    try {  // no exception may cross the C ABI: if the helper cannot start, pack serially
-      std::thread helper(pack, 0, ref_planes, ref_strides);
-      pack(1, dis_planes, dis_strides);
-      helper.join();
+  bool pooled = false;
+  if (c->slot_bytes >= (4u << 20)) {
+    try {  // no exception may cross the C ABI: if the helpers cannot start, pack serially
+      if (!c->pack_pool_tried) {
+        c->pack_pool_tried = true;
+        const char* e = getenv("PQA_PACK_THREADS");  // threads packing a frame, the caller included (default 4)
+        int n = e ? atoi(e) : 4;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && n > hw) n = hw;
+        if (n > 1) c->pack_pool.reset(new PackPool(n - 1));
+      }
+      if (c->pack_pool) {
+        c->pack_tasks.clear();
+        for (int side = 0; side < 2; ++side) {
+          const void* const* planes = side ? dis_planes : ref_planes;
+          const int64_t* strides = side ? dis_strides : ref_strides;
+          for (int p = 0; p < c->n_planes; ++p) {
+            const size_t row_bytes = (size_t)c->pw[p] * c->esize;
+            int rows_per = (int)((1u << 20) / (row_bytes ? row_bytes : 1));
+            if (rows_per < 1) rows_per = 1;
+            for (int y = 0; y < c->ph[p]; y += rows_per) {
+              const int rows = c->ph[p] - y < rows_per ? c->ph[p] - y : rows_per;
+              c->pack_tasks.push_back(PackTask{slot + c->plane_off[side][p] + (int64_t)y * c->slot_row_pitch[p],
+                                               (const uint8_t*)planes[p] + (int64_t)y * strides[p],
+                                               c->slot_row_pitch[p], strides[p], row_bytes, rows});
+            }
+          }
+        }
+        c->pack_pool->run(c->pack_tasks.data(), (int)c->pack_tasks.size());
+        pooled = true;
+      }
     } catch (...) {
-      split = false;
+      c->pack_pool.reset();
+      pooled = false;
     }
   }
-  if (!split) {
+  if (!pooled) {
     pack(0, ref_planes, ref_strides);
     pack(1, dis_planes, dis_strides);
   }
