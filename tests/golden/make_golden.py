@@ -15,6 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle.int_oracle import IntOracle  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 from pqa2_amd import model as M, synth  # noqa: E402
 
@@ -24,8 +25,11 @@ CASES = [("c64x48_8", 64, 48, 8, 3), ("c176x144_8", 176, 144, 8, 3), ("c321x241_
 
 def main():
     o64 = Oracle("f64")
+    into = IntOracle()
     out = {"note": "f64 oracle on pqa2_amd.synth.make_clip(w,h,n,bpc,chroma=True); records = vif num[4], vif den[4], "
-                   "adm num[4], adm den[4], motion; sse/ssim per plane (FFmpeg psnr/ssim definitions)", "cases": {}}
+                   "adm num[4], adm den[4], motion; sse/ssim per plane (FFmpeg psnr/ssim definitions); "
+                   "records_fixed_point = the same layout from oracle/vmaf_int_oracle.c (integer arithmetic: exact)",
+           "cases": {}}
     mdl = M.load_model("vmaf_v0.6.1")
     for name, w, h, bpc, n in CASES:
         refs, diss = synth.make_clip(w, h, n, bpc, chroma=True)
@@ -38,8 +42,10 @@ def main():
         vm = M.score_frames(mdl, M.metrics_from_records(full, w, h, "integer_"))["vmaf"]
         sse = [[o64.sse_plane(diss[i][p], refs[i][p], bpc) for p in range(3)] for i in range(n)]
         ssim = [[o64.ssim_plane(diss[i][p], refs[i][p], bpc) for p in range(3)] for i in range(n)]
+        rec_fx = into.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc)
         out["cases"][name] = {"w": w, "h": h, "bpc": bpc, "n": n, "input_sha256": sha.hexdigest(),
-                              "records": rec.tolist(), "vmaf_v0.6.1": vm.tolist(), "sse": sse, "ssim": ssim}
+                              "records": rec.tolist(), "vmaf_v0.6.1": vm.tolist(), "sse": sse, "ssim": ssim,
+                              "records_fixed_point": rec_fx.tolist()}
         if name == "c64x48_8":  # ship the actual bytes of the smallest case
             np.savez_compressed(os.path.join(HERE, "c64x48_8_frames.npz"),
                                 **{f"ref{i}_{p}": refs[i][p] for i in range(n) for p in range(3)},

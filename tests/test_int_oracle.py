@@ -90,3 +90,31 @@ def test_identical_frames(into):
     np.testing.assert_allclose(v[:4] / v[4:], 1.0, atol=2e-4)
     assert np.all(v[:4] <= v[4:])
     np.testing.assert_allclose(a[:4] / a[4:], 1.0, atol=2e-5)
+
+
+def test_fixed_point_golden_fixtures(into):
+    """Regression anchors for the fixed-point restatement (tests/golden/make_golden.py): integer arithmetic, so the
+    stored doubles must come back bit for bit -- from the shipped bytes of the smallest case and, when the synthetic
+    generator reproduces its inputs, from the regenerated ones."""
+    import hashlib
+    import json
+    import os
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    with open(os.path.join(gold_dir, "golden_features.json")) as f:
+        gold = json.load(f)["cases"]
+    g = gold["c64x48_8"]
+    z = np.load(os.path.join(gold_dir, "c64x48_8_frames.npz"))
+    R = [z[f"ref{i}_0"] for i in range(g["n"])]
+    D = [z[f"dis{i}_0"] for i in range(g["n"])]
+    assert np.array_equal(into.clip_features(R, D, 8), np.array(g["records_fixed_point"]))
+    for name in ("c176x144_8", "c200x120_10"):
+        g = gold[name]
+        refs, diss = synth.make_clip(g["w"], g["h"], g["n"], g["bpc"], chroma=True)
+        sha = hashlib.sha256()
+        for fr in refs + diss:
+            for p in fr:
+                sha.update(np.ascontiguousarray(p).tobytes())
+        if sha.hexdigest() != g["input_sha256"]:
+            pytest.skip("synthetic generator produced different bytes on this numpy build")
+        got = into.clip_features([r[0] for r in refs], [d[0] for d in diss], g["bpc"])
+        assert np.array_equal(got, np.array(g["records_fixed_point"])), name
