@@ -421,3 +421,36 @@ def test_fixed_point_random_geometry_sweep():
             got = eng.collect(0, 2)[:, :17]
         bad = np.argwhere(got.view(np.uint64) != want.view(np.uint64))
         assert bad.size == 0, (w, h, kind, bpc, bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
+
+
+def test_against_committed_golden_fixtures():
+    """The HIP path against tests/golden/ (no oracle at run time): f32 kernels within the stated tolerances of the
+    f64 fixture, PSNR SSE exact, SSIM 1e-9, VMAF 0.01; the fixed-point kernels bit-equal to the fixed-point fixture."""
+    import json
+    import os
+    from pqa2_amd import _native as N
+    from pqa2_amd import model as M
+    from pqa2_amd.engine import sse_from_records
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    with open(os.path.join(gold_dir, "golden_features.json")) as f:
+        g = json.load(f)["cases"]["c64x48_8"]
+    z = np.load(os.path.join(gold_dir, "c64x48_8_frames.npz"))
+    n, w, h = g["n"], g["w"], g["h"]
+    refs = [[z[f"ref{i}_{p}"] for p in range(3)] for i in range(n)]
+    diss = [[z[f"dis{i}_{p}"] for p in range(3)] for i in range(n)]
+    with _engine(w, h, n_planes=3, features=N.FEAT_ALL) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        rec = eng.collect(0, n)
+    want = np.array(g["records"])
+    rel = np.abs(rec[:, :16] - want[:, :16]) / np.maximum(np.abs(want[:, :16]), 1e-12)
+    assert rel.max() < REL_TOL and np.abs(rec[:, 16] - want[:, 16]).max() < MOTION_ATOL
+    assert sse_from_records(rec).tolist() == g["sse"]
+    assert np.abs(rec[:, N.REC_SSIM:N.REC_SSIM + 3] - np.array(g["ssim"])).max() < 1e-9
+    vm = M.score_frames(M.load_model("vmaf_v0.6.1"), M.metrics_from_records(rec, w, h, "integer_"))["vmaf"]
+    assert np.abs(vm - np.array(g["vmaf_v0.6.1"])).max() < 0.01
+    with _engine(w, h, fixed_point=N.FIXED_ALL) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i][:1], diss[i][:1])
+        fx = eng.collect(0, n)[:, :17]
+    assert np.array_equal(fx, np.array(g["records_fixed_point"]))
