@@ -60,3 +60,51 @@ def test_bad_arguments_do_not_crash():
     assert lib.pqa_create(C.byref(cfg), C.byref(ctx)) == N.PQA_EINVAL and b"frame size" in lib.pqa_last_error(None)
     lib.pqa_destroy(None)
     assert lib.pqa_cancel(None) == N.PQA_EINVAL
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/pqa_vmaf.h must be consumable by a C compiler (the boundary is a C ABI, not C++): compile a C99
+    program against it with gcc, link it to the library, run it on this GPU-less host.  It checks the struct
+    layout the Python binding assumes and that creation fails with PQA_EDEVICE/EINVAL instead of crashing."""
+    import shutil
+    import subprocess
+    from pqa2_amd import _native as N
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    if not os.path.exists(N.LIB_PATH):
+        N.build()
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include "pqa_vmaf.h"
+int main(void) {
+  pqa_config cfg;
+  pqa_ctx* ctx = NULL;
+  int rc;
+  pqa_config_init(&cfg, 1920, 1080);
+  printf("%zu %zu %zu %zu %d %u\n", sizeof(pqa_config), offsetof(pqa_config, vif_enhn_gain_limit),
+         offsetof(pqa_config, vif_border), offsetof(pqa_config, fixed_point), PQA_RECORD_DOUBLES, cfg.struct_size);
+  cfg.fixed_point = PQA_FIXED_ALL;
+  cfg.vif_border = PQA_VIF_BORDER_INTEGER;
+  rc = pqa_create(&cfg, &ctx);
+  printf("%d %s\n", rc, pqa_last_error(NULL));
+  if (ctx) pqa_destroy(ctx);
+  return strstr(pqa_version(), "gfx950") ? 0 : 1;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(N.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-o", str(exe), "-L", libdir, "-lpqa_vmaf", f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    first, second = r.stdout.strip().split("\n")
+    size, off_gain, off_border, off_fixed, rec, struct_size = map(int, first.split())
+    assert size == C.sizeof(N.PqaConfig) == struct_size and rec == 24
+    assert off_gain == N.PqaConfig.vif_enhn_gain_limit.offset
+    assert off_border == N.PqaConfig.vif_border.offset and off_fixed == N.PqaConfig.fixed_point.offset
+    import torch
+    if not torch.cuda.is_available():
+        assert second.startswith(str(N.PQA_EDEVICE)) and "no CPU fallback" in second
