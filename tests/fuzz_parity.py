@@ -3,7 +3,7 @@
 and VIF borders through the HIP library, against the oracles.  f32 kernels: relative tolerance max(5e-5, 8 x the f32
 oracle's own distance from f64) -- smooth content on tiny planes makes sigma = E[x^2] - mu^2 cancel to ~1e-3 per pixel in
 ANY f32 evaluation order, libvmaf's included, so the bar scales with what f32 itself can hold; fixed-point kernels:
-bit-equality.   usage: python tests/fuzz_parity.py [seconds] [seed]"""
+bit-equality.   usage: python tests/fuzz_parity.py [seconds] [seed] [hd]"""
 import os
 import sys
 import time
@@ -19,6 +19,7 @@ from pqa2_amd.engine import FeatureEngine
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+hd_only = len(sys.argv) > 3 and sys.argv[3] == "hd"   # only frames of the sizes the 0.01 VMAF target is stated for
 rng = np.random.default_rng(seed)
 o64, o32, into = Oracle("f64"), Oracle("f32"), IntOracle()
 t0 = time.time()
@@ -40,7 +41,7 @@ def vmaf(rec17, w, h):
 
 
 while time.time() - t0 < budget:
-    if rng.integers(0, 12) == 0:   # now and then a frame of the sizes the 0.01 VMAF target is stated for
+    if hd_only or rng.integers(0, 12) == 0:   # now and then a frame of the sizes the 0.01 VMAF target is stated for
         w, h = int(rng.integers(900, 1930)), int(rng.integers(540, 1090))
     else:
         w, h = int(rng.integers(16, 700)), int(rng.integers(16, 400))
