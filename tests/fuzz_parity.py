@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long randomized parity run (not collected by pytest): random geometries, bit depths, content kinds, gain limits
-and VIF borders through the HIP library, against the oracles.  f32 kernels: relative tolerance max(5e-5, 8 x the f32
+and VIF borders (plus random chroma subsampling for the exact PSNR SSE and the SSIM) through the HIP library, against the
+oracles.  f32 kernels: relative tolerance max(5e-5, 8 x the f32
 oracle's own distance from f64) -- smooth content on tiny planes makes sigma = E[x^2] - mu^2 cancel to ~1e-3 per pixel in
 ANY f32 evaluation order, libvmaf's included, so the bar scales with what f32 itself can hold; fixed-point kernels:
 bit-equality.   usage: python tests/fuzz_parity.py [seconds] [seed] [hd]"""
@@ -15,7 +16,7 @@ from oracle.int_oracle import IntOracle
 from oracle.oracle import Oracle
 from pqa2_amd import _native as N
 from pqa2_amd import model as M
-from pqa2_amd.engine import FeatureEngine
+from pqa2_amd.engine import FeatureEngine, sse_from_records
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -70,11 +71,25 @@ while time.time() - t0 < budget:
     tag = (w, h, bpc, kind, gain, border)
     exp = o64.clip_features(frames, dis, bpc, vif_gain_limit=gain, adm_gain_limit=gain, vif_border101=bool(border))
     exp32 = o32.clip_features(frames, dis, bpc, vif_gain_limit=gain, adm_gain_limit=gain, vif_border101=bool(border))
-    with FeatureEngine(w, h, bit_depth=bpc, vif_enhn_gain_limit=gain, adm_enhn_gain_limit=gain, vif_border=border,
+    # chroma planes for the FFmpeg psnr / ssim side features: random subsampling, own noise
+    hs, vs = [(1, 1), (1, 0), (0, 0)][int(rng.integers(0, 3))]
+    cw, ch = -(-w >> hs), -(-h >> vs)
+    dt = np.uint8 if bpc == 8 else np.uint16
+    cref = [[rng.integers(0, peak + 1, (ch, cw)).astype(dt) for _ in range(2)] for _ in range(n)]
+    cdis = [[np.clip(p.astype(np.int32) + rng.integers(-amp, amp + 1, p.shape), 0, peak).astype(dt) for p in fr] for fr in cref]
+    with FeatureEngine(w, h, bit_depth=bpc, n_planes=3, chroma_shift=(hs, vs), features=N.FEAT_ALL,
+                       vif_enhn_gain_limit=gain, adm_enhn_gain_limit=gain, vif_border=border,
                        max_batch=int(rng.integers(1, 4)) + 7) as eng:
         for i in range(n):
-            eng.submit(i, [frames[i]], [dis[i]])
-        got = eng.collect(0, n)[:, :17]
+            eng.submit(i, [frames[i]] + cref[i], [dis[i]] + cdis[i])
+        rec = eng.collect(0, n)
+    got = rec[:, :17]
+    sse = sse_from_records(rec)
+    for i in range(n):
+        for p, (a_, b_) in enumerate(zip([dis[i]] + cdis[i], [frames[i]] + cref[i])):
+            assert int(sse[i, p]) == o32.sse_plane(a_, b_, bpc), ("sse", tag, i, p)
+            if min(a_.shape) >= 8:
+                assert abs(rec[i, N.REC_SSIM + p] - o32.ssim_plane(a_, b_, bpc)) < 1e-9, ("ssim", tag, i, p)
     assert np.all(np.isfinite(got)), ("non-finite", tag)
     # distance to the nearer of the two oracles: where f32 and f64 disagree (a branch decided at a 1e-8 margin), agreeing
     # with libvmaf's own arithmetic type is as right as agreeing with the f64 truth
