@@ -235,7 +235,17 @@ def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads, gpu_records,
     rec[:, :17] = exp
     v_cpu = M.score_frames(model, M.metrics_from_records(rec, w, h, prefix))["vmaf"]
     v_gpu = M.score_frames(model, M.metrics_from_records(gpu_records[:n_sample], w, h, prefix))["vmaf"]
+    # the same frames through the fixed-point restatement: the arithmetic libvmaf's DEFAULT models run on a CPU
+    # (integer_vif / integer_adm / integer_motion), again one frame per thread
+    from oracle.int_oracle import IntOracle
+    into = IntOracle()
+    n_fx = min(n_sample, 2 * threads)
+    t0 = time.perf_counter()
+    into.clip_features_mt(refs[:n_fx], diss[:n_fx], bpc, threads, model.vif_enhn_gain_limit, model.adm_enhn_gain_limit)
+    dt_fx = time.perf_counter() - t0
     return {"value": round(n_sample / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "fixed_point_port_value": round(n_fx / dt_fx, 4),
+            "fixed_point_port_sample": f"first {n_fx} frames, oracle/vmaf_int_oracle.c, {dt_fx:.1f} s on {threads} threads",
             "sample": f"first {n_sample} frames of the same clip, oracle/vmaf_oracle.c f32 (VIF+ADM+motion), "
                       f"{dt:.1f} s on {threads} threads (one frame each) of {os.cpu_count()} host cores; "
                       f"ffmpeg/libvmaf not present on this box",

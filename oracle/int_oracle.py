@@ -32,6 +32,8 @@ class IntOracle:
         for fn in (L.orc_int_vif, L.orc_int_adm):
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        L.orc_int_init.restype = None
+        L.orc_int_init()
         L.orc_int_log2_entry.restype = C.c_uint16
         L.orc_int_log2_entry.argtypes = [C.c_int]
 
@@ -81,4 +83,22 @@ class IntOracle:
                 f[16] = self.motion_score(self.motion_sad(prev, blur), w, h)
             prev = blur
             out.append(f)
+        return np.stack(out) if out else np.zeros((0, N_FEAT))
+
+    def clip_features_mt(self, ref_frames, dis_frames, bpc: int = 8, threads: int = 4, vif_gain_limit: float = 100.0,
+                         adm_gain_limit: float = 100.0) -> np.ndarray:
+        """clip_features on a thread pool (ctypes releases the GIL): frame i blurs reference frame i-1 itself."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(i):
+            f = np.zeros(N_FEAT)
+            f[0:8] = self.vif(ref_frames[i], dis_frames[i], bpc, vif_gain_limit)
+            f[8:16] = self.adm(ref_frames[i], dis_frames[i], bpc, adm_gain_limit)
+            if i > 0:
+                a, b = self.motion_blur(ref_frames[i - 1], bpc), self.motion_blur(ref_frames[i], bpc)
+                f[16] = self.motion_score(self.motion_sad(a, b), b.shape[1], b.shape[0])
+            return f
+
+        with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+            out = list(ex.map(one, range(len(ref_frames))))
         return np.stack(out) if out else np.zeros((0, N_FEAT))

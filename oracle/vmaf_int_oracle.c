@@ -302,6 +302,9 @@ static void div_lookup_generator(void)
     g_div_ready = 1;
 }
 
+/* builds both lookup tables up front (the lazy paths are not safe to race from a thread pool) */
+ORC_EXPORT void orc_int_init(void) { log_generate(); div_lookup_generator(); }
+
 /* Watson DWT 7/9 model in float, as adm_tools.h dwt_quant_step() */
 static float int_dwt_quant_step(int lambda, int theta)
 {
