@@ -108,3 +108,21 @@ int main(void) {
     import torch
     if not torch.cuda.is_available():
         assert second.startswith(str(N.PQA_EDEVICE)) and "no CPU fallback" in second
+
+
+def test_integration_doc_binding_matches_the_header():
+    """INTEGRATION.md shows the ctypes stub a PQA2 maintainer would add; its pqa_config field list must be the
+    header's (and so the binding's), in order -- a drifted doc would corrupt memory in pqa_config_init."""
+    from pqa2_amd import _native as N
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class PqaConfig(C.Structure):"):doc.index("lib = C.CDLL")]
+    doc_fields = re.findall(r'\("(\w+)",\s*C\.c_(\w+)\)', block)
+    want = [(n, t.__name__.replace("c_", "")) for n, t in N.PqaConfig._fields_]
+    assert [(n, {"uint": "uint32", "int": "int32"}.get(t, t)) for n, t in doc_fields] == \
+           [(n, {"uint": "uint32", "int": "int32"}.get(t, t)) for n, t in want]
+    hdr = open(os.path.join(ROOT, "include", "pqa_vmaf.h")).read()
+    struct = hdr[hdr.index("typedef struct pqa_config {"):hdr.index("} pqa_config;")]
+    hdr_fields = []
+    for decl in re.findall(r"^\s*(?:uint32_t|int32_t|double)\s+([\w\s,]+);", struct, re.M):
+        hdr_fields += [f.strip() for f in decl.split(",")]
+    assert hdr_fields == [n for n, _ in N.PqaConfig._fields_]
