@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the extra 1080p measurement the default 2160p run appends as `other_configs`")
     ap.add_argument("--fixed-point", type=int, default=0,
                     help="PQA_FIXED_* mask (1 VIF, 2 motion): measure libvmaf's fixed-point arithmetic instead of the "
                          "default f32 path")
@@ -196,10 +198,27 @@ def main():
             n_sample = args.cpu_sample_frames or max(2, min(F, threads * max(1, int(12.0 / (w * h * 2.0e-7)))))
             out["cpu_baseline"] = _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads,
                                                 result["records"], model, prefix)
+        if world == 1 and args.workload == "2160p" and not args.fixed_point and not args.no_other_configs:
+            out["other_configs"] = _other_configs(args)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _other_configs(args):
+    """BASELINE.json names 1080p (configs[1]) next to the 4K headline: measure it too, in a child process with the same
+    step definition (its own context and clip), and carry its line's essentials along.  Never part of `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "1080p", "--steps", str(max(3, args.steps)),
+           "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-other-configs"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"1080p": {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                          "workload": d["config"]["workload"], "roofline_frac": d.get("roofline", {}).get("frac")}}
+    except Exception as e:  # the headline must not depend on this
+        return {"1080p": {"error": str(e)[:200]}}
 
 
 def _traffic_from_profiles(workload: str):
