@@ -40,7 +40,10 @@ typedef enum pqa_status {
   PQA_EDEVICE = -2,    /* HIP runtime failure (text in pqa_last_error) */
   PQA_ENOMEM = -3,     /* host or device allocation failed */
   PQA_ECANCELLED = -4, /* pqa_cancel() was called; pqa_reset() re-arms the context */
-  PQA_ESTATE = -5      /* call sequence error (e.g. collecting frames never submitted) */
+  PQA_ESTATE = -5      /* call sequence error: collecting a frame that was never submitted (or whose record a
+                          later frame has replaced), or submitting a frame whose ring slot still holds the
+                          UNCOLLECTED record of a different frame (result_capacity too small for the caller's
+                          collect cadence).  Nothing is launched or overwritten when this is returned. */
 } pqa_status;
 
 /* feature mask: which extractors run per frame */
@@ -151,8 +154,11 @@ PQA_API int pqa_set_motion_halo(pqa_ctx* ctx, const void* prev_ref_luma_host, in
 /* Launch whatever pqa_submit has pending (partial batch). */
 PQA_API int pqa_flush(pqa_ctx* ctx);
 
-/* Wait for all submitted work, then copy `count` records starting at frame first_index into
- * records[count][PQA_RECORD_DOUBLES].  Replaces reading the libvmaf JSON log / stats files. */
+/* Copy `count` records starting at frame first_index into records[count][PQA_RECORD_DOUBLES].  Launches a pending
+ * partial batch, then waits only for the batch that produced the youngest requested record (one completion event
+ * per batch): batches submitted later keep running while the caller works on these records (SVM, pooling).
+ * Frames that were never submitted, or whose record has been replaced, give PQA_ESTATE.  A collected record's ring
+ * slot becomes free for frame index + k * result_capacity.  Replaces reading the libvmaf JSON log / stats files. */
 PQA_API int pqa_collect(pqa_ctx* ctx, int64_t first_index, int32_t count, double* records);
 
 /* Wait for all submitted work without collecting. */

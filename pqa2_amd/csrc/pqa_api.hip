@@ -2,6 +2,7 @@
 // Declarations and the reference interfaces each entry point replaces: include/pqa_vmaf.h.
 #include "../../include/pqa_vmaf.h"
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
@@ -41,6 +42,9 @@ struct ProfEv {
   int id, frames;
 };
 
+constexpr int kBatchEvents = 64;  // ring of per-batch completion events
+enum : uint8_t { kSlotEmpty = 0, kSlotSubmitted = 1, kSlotCollected = 2 };
+
 // pqa_submit packs the caller's planes into pinned staging.  One core's memcpy (~10 GB/s) is far below PCIe, so the
 // rows of a frame pair are split into ~1 MiB tasks that a few persistent helper threads and the caller drain together.
 struct PackTask {
@@ -54,16 +58,16 @@ struct PackTask {
 class PackPool {
  public:
   explicit PackPool(int helpers) {
-    for (int i = 0; i < helpers; ++i) workers_.emplace_back([this] { loop(); });
-  }
-  ~PackPool() {
-    {
-      std::lock_guard<std::mutex> g(m_);
-      stop_ = true;
+    try {
+      for (int i = 0; i < helpers; ++i) workers_.emplace_back([this] { loop(); });
+    } catch (...) {
+      // a std::thread that cannot start (EAGAIN, RLIMIT_NPROC) throws while earlier workers are joinable: unwinding
+      // the vector would call std::terminate.  Stop and join what did start, then let the caller fall back to serial.
+      shutdown();
+      throw;
     }
-    cv_work_.notify_all();
-    for (auto& t : workers_) t.join();
   }
+  ~PackPool() { shutdown(); }
   void run(const PackTask* tasks, int n) {
     {
       std::lock_guard<std::mutex> g(m_);
@@ -76,6 +80,16 @@ class PackPool {
   }
 
  private:
+  void shutdown() noexcept {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto& t : workers_)
+      if (t.joinable()) t.join();
+    workers_.clear();
+  }
   void drain() {
     for (;;) {
       const int i = next_.fetch_add(1);
@@ -167,6 +181,15 @@ struct pqa_ctx {
   std::unique_ptr<PackPool> pack_pool;
   bool pack_pool_tried = false;
   std::vector<PackTask> pack_tasks;
+  // record-ring bookkeeping (host side): which frame a slot holds, whether it was collected, and the batch that
+  // writes it.  Lets pqa_collect wait for ITS batch only and makes the PQA_ESTATE promises of the header real.
+  std::vector<int64_t> slot_frame;   // -1: nothing submitted into this slot
+  std::vector<uint8_t> slot_state;   // kSlotEmpty / kSlotSubmitted / kSlotCollected
+  std::vector<uint64_t> slot_seq;    // sequence number of the batch whose finalize writes the slot
+  hipEvent_t batch_ev[kBatchEvents] = {};
+  uint64_t batch_ev_seq[kBatchEvents] = {};  // sequence number last recorded into each event
+  uint64_t batch_seq = 0;            // batches launched so far (the next batch gets batch_seq + 1)
+  uint64_t done_seq = 0;             // every batch <= done_seq is known to be complete
   std::atomic<int> cancelled{0};
   std::string err;
   std::vector<void*> allocs;
@@ -249,6 +272,41 @@ void prof_drain(pqa_ctx* c) {
   c->evs.clear();
 }
 
+// ---- record-ring bookkeeping -----------------------------------------------------------------------
+// A slot may be rewritten by the SAME frame index (a re-run) or once its record has been collected; a different
+// frame landing on an uncollected record would lose it silently, so that is a call-sequence error.
+int check_slots_free(pqa_ctx* c, int64_t first, int n) {
+  for (int i = 0; i < n; ++i) {
+    const int64_t f = first + i;
+    const size_t s = (size_t)(f % c->capacity);
+    if (c->slot_state[s] == kSlotSubmitted && c->slot_frame[s] != f)
+      return fail(c, PQA_ESTATE,
+                  "frame %lld would overwrite the uncollected record of frame %lld (result_capacity %d): "
+                  "collect it first or create the context with a larger result_capacity",
+                  (long long)f, (long long)c->slot_frame[s], c->capacity);
+  }
+  return PQA_OK;
+}
+
+void claim_slots(pqa_ctx* c, int64_t first, int n, uint64_t seq) {
+  for (int i = 0; i < n; ++i) {
+    const size_t s = (size_t)((first + i) % c->capacity);
+    c->slot_frame[s] = first + i;
+    c->slot_state[s] = kSlotSubmitted;
+    c->slot_seq[s] = seq;
+  }
+}
+
+// Wait until batch `seq` (and, the stream being in order, every earlier one) has written its records.
+int wait_batch(pqa_ctx* c, uint64_t seq) {
+  if (seq <= c->done_seq) return PQA_OK;
+  const int e = (int)(seq % kBatchEvents);
+  // the event may meanwhile carry a later batch of the same stream: waiting for that one is still correct
+  HIPCHK(c, hipEventSynchronize(c->batch_ev[e]));
+  c->done_seq = c->batch_ev_seq[e] > seq ? c->batch_ev_seq[e] : seq;
+  return PQA_OK;
+}
+
 // ---- the batch: every kernel for n consecutive device-resident frames -------------------------
 int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, const pqa_device_clip* dis,
                   const void* prev, int64_t prev_pitch_bytes) {
@@ -258,6 +316,10 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     if (ref->row_pitch[p] % es || dis->row_pitch[p] % es || ref->frame_pitch[p] % es || dis->frame_pitch[p] % es)
       return fail(c, PQA_EINVAL, "plane %d pitch is not a multiple of the sample size", p);
     if (!ref->plane[p] || !dis->plane[p]) return fail(c, PQA_EINVAL, "plane %d pointer is null", p);
+  }
+  {
+    const int rc = check_slots_free(c, first, n);
+    if (rc != PQA_OK) return rc;
   }
   const PlaneRun rY{ref->plane[0], ref->row_pitch[0] / es, ref->frame_pitch[0] / es};
   const PlaneRun dY{dis->plane[0], dis->row_pitch[0] / es, dis->frame_pitch[0] / es};
@@ -498,6 +560,14 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       HIPCHK(c, launch_finalize(st, fa));
     }
   }
+  {  // the records of this batch are complete here: one event per batch, so pqa_collect waits for ITS batch only
+    const uint64_t seq = c->batch_seq + 1;
+    const int e = (int)(seq % kBatchEvents);
+    HIPCHK(c, hipEventRecord(c->batch_ev[e], st));
+    c->batch_ev_seq[e] = seq;
+    c->batch_seq = seq;
+    claim_slots(c, first, n, seq);
+  }
   if (feat & PQA_FEAT_MOTION) {
     // keep the last reference luma so the next batch continues the motion chain
     const uint8_t* src = (const uint8_t*)ref->plane[0] + (int64_t)(n - 1) * ref->frame_pitch[0];
@@ -656,6 +726,15 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     CREATE_HIP(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
   }
   CREATE_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+  for (int i = 0; i < kBatchEvents; ++i) CREATE_HIP(hipEventCreateWithFlags(&c->batch_ev[i], hipEventDisableTiming));
+  try {
+    c->slot_frame.assign((size_t)c->capacity, -1);
+    c->slot_state.assign((size_t)c->capacity, kSlotEmpty);
+    c->slot_seq.assign((size_t)c->capacity, 0);
+  } catch (...) {
+    fail(c, PQA_ENOMEM, "out of host memory");
+    return bail(PQA_ENOMEM);
+  }
 
   c->vif_fixed = (cfg->features & PQA_FEAT_VIF) && (cfg->fixed_point & PQA_FIXED_VIF);
   c->motion_fixed = (cfg->features & PQA_FEAT_MOTION) && (cfg->fixed_point & PQA_FIXED_MOTION);
@@ -764,6 +843,7 @@ void pqa_destroy(pqa_ctx* c) {
     if (c->join_ev[i]) hipEventDestroy(c->join_ev[i]);
   }
   if (c->fork_ev) hipEventDestroy(c->fork_ev);
+  for (int i = 0; i < kBatchEvents; ++i) if (c->batch_ev[i]) hipEventDestroy(c->batch_ev[i]);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -772,6 +852,7 @@ int pqa_set_stream(pqa_ctx* c, void* hip_stream) {
   if (!c) return PQA_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->done_seq = c->batch_seq;
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return PQA_OK;
 }
@@ -818,7 +899,11 @@ int pqa_submit(pqa_ctx* c, int64_t frame_index, const void* const ref_planes[3],
     return fail(c, PQA_EINVAL, "bad argument");
   if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = ensure_staging(c);
+  int rc = check_slots_free(c, frame_index, 1);  // before anything is packed: the caller can collect and retry
+  if (rc != PQA_OK) return rc;
+  if (c->pending >= c->capacity)
+    return fail(c, PQA_ESTATE, "more pending frames than result_capacity %d", c->capacity);
+  rc = ensure_staging(c);
   if (rc != PQA_OK) return rc;
   if (c->pending > 0 && frame_index != c->pending_first + c->pending) {
     rc = flush_pending(c);  // non-consecutive index starts a new run
@@ -927,6 +1012,7 @@ int pqa_sync(pqa_ctx* c) {
   int rc = c->cancelled.load() ? PQA_OK : flush_pending(c);
   if (rc != PQA_OK) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->done_seq = c->batch_seq;
   prof_drain(c);
   if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
   return PQA_OK;
@@ -936,8 +1022,27 @@ int pqa_collect(pqa_ctx* c, int64_t first_index, int32_t count, double* records)
   if (!c) return PQA_EINVAL;
   if (count < 0 || first_index < 0 || (count > 0 && !records)) return fail(c, PQA_EINVAL, "bad argument");
   if (count > c->capacity) return fail(c, PQA_ESTATE, "count %d exceeds result_capacity %d", count, c->capacity);
-  int rc = pqa_sync(c);
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = flush_pending(c);  // a partial host batch holding requested frames has to be launched first
   if (rc != PQA_OK) return rc;
+  // every requested frame must be the one its ring slot holds (never submitted / overwritten -> PQA_ESTATE);
+  // then wait for the youngest batch among them only -- later batches keep running under the host's work
+  uint64_t need = 0;
+  for (int i = 0; i < count; ++i) {
+    const int64_t f = first_index + i;
+    const size_t s = (size_t)(f % c->capacity);
+    if (c->slot_state[s] == kSlotEmpty || c->slot_frame[s] != f) {
+      if (c->slot_state[s] == kSlotEmpty)
+        return fail(c, PQA_ESTATE, "frame %lld was never submitted", (long long)f);
+      return fail(c, PQA_ESTATE, "frame %lld was never submitted, or its record was overwritten by frame %lld",
+                  (long long)f, (long long)c->slot_frame[s]);
+    }
+    if (c->slot_seq[s] > need) need = c->slot_seq[s];
+  }
+  rc = wait_batch(c, need);
+  if (rc != PQA_OK) return rc;
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
   const size_t rec_bytes = PQA_RECORD_DOUBLES * sizeof(double);
   int64_t row = first_index % c->capacity;
   int done = 0;
@@ -965,6 +1070,7 @@ int pqa_collect(pqa_ctx* c, int64_t first_index, int32_t count, double* records)
     done += n;
     row = 0;
   }
+  for (int i = 0; i < count; ++i) c->slot_state[(size_t)((first_index + i) % c->capacity)] = kSlotCollected;
   return PQA_OK;
 }
 
@@ -999,6 +1105,9 @@ int pqa_reset(pqa_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
   c->cancelled.store(0);
+  c->done_seq = c->batch_seq;
+  std::fill(c->slot_frame.begin(), c->slot_frame.end(), (int64_t)-1);
+  std::fill(c->slot_state.begin(), c->slot_state.end(), (uint8_t)kSlotEmpty);
   c->pending = 0;
   c->have_last = false;
   c->halo_armed = false;

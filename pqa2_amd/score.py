@@ -27,6 +27,9 @@ def main(argv=None) -> int:
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--fixed-point", type=int, default=0,
                     help="PQA_FIXED_* mask (1 VIF, 2 motion): extractors run in libvmaf's fixed-point arithmetic")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend of the record gather; gloo + --share-device rehearses N ranks on one GPU")
+    ap.add_argument("--share-device", action="store_true", help="every rank uses device 0 (rehearsal on a one-GPU box)")
     a = ap.parse_args(argv)
 
     from . import report
@@ -35,12 +38,17 @@ def main(argv=None) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     gather_device = None
+    if a.share_device:
+        local_rank = 0
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        gather_device = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", device_id=gather_device)
+        if a.backend == "nccl":      # RCCL: the records travel GPU to GPU over xGMI
+            gather_device = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=gather_device)
+        else:                        # gloo: host tensors (several ranks may then share one GPU)
+            dist.init_process_group("gloo")
     last = [0.0]
 
     def progress(done, total):

@@ -27,12 +27,15 @@ def all_bounds(n_frames: int, world_size: int):
     return [shard_bounds(n_frames, world_size, r) for r in range(world_size)]
 
 
-def gather_records(local: np.ndarray, n_frames: int, world_size: int, rank: int, device=None):
+def gather_records(local: np.ndarray, n_frames: int, world_size: int, rank: int, device=None,
+                   force_collective: bool = False):
     """All-gather the per-rank record tiles into the full [n_frames, 24] array (on every rank).
 
     One collective: equal-sized tiles of ceil(n/world) rows (short ranks pad with zeros).  float64
-    payload carries the uint64 SSE slots bit-exactly (no arithmetic touches them)."""
-    if world_size == 1:
+    payload carries the uint64 SSE slots bit-exactly (no arithmetic touches them).
+    `force_collective`: run the collective even at world_size 1 (a one-rank process group) -- how the RCCL leg is
+    exercised on a one-GPU box."""
+    if world_size == 1 and not force_collective:
         return np.asarray(local, np.float64).reshape(-1, RECORD_DOUBLES)
     import torch
     import torch.distributed as dist

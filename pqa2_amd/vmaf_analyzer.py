@@ -100,6 +100,8 @@ class VMAFAnalyzer(QObject):
         self.device = 0                       # HIP device ordinal for single-process runs
         self.gpus = 1                         # >1: frame-sharded child job, one process per GPU
         self.max_batch = 0                    # 0: the library sizes launches itself
+        self.child_backend = "nccl"           # collective backend of the child job: nccl (= RCCL) | gloo
+        self.child_share_device = False       # True: every rank of the child job uses device 0 (one-GPU rehearsal)
         self.fixed_point = 0                  # PQA_FIXED_* mask (1 VIF, 2 motion): libvmaf's integer arithmetic, slower
         self.last_fps = 0.0
         self._engine_factory = None           # tests inject a stand-in; product code leaves it None
@@ -148,12 +150,35 @@ class VMAFAnalyzer(QObject):
         proc = self._current_process
         if proc is not None:
             try:
-                proc.terminate()
-                time.sleep(0.5)
-                if proc.poll() is None:
-                    proc.kill()
+                self._stop_child(proc)
             except Exception as e:
                 logger.error(f"Error terminating VMAF process: {e}")
+
+    @staticmethod
+    def _stop_child(proc, grace=3.0):
+        """The child job is a torchrun agent PLUS one worker per GPU (the reference had a single ffmpeg child).  It is
+        started as its own session, so SIGTERM goes to the whole process group, and after `grace` seconds SIGKILL does:
+        no worker is left behind holding a GPU context or blocked in the RCCL gather."""
+        import signal
+        if proc.poll() is not None:
+            return
+        try:
+            pgid = os.getpgid(proc.pid)
+        except ProcessLookupError:
+            return
+        own_group = pgid == proc.pid      # only signal a group this analyzer created (start_new_session=True)
+        try:
+            os.killpg(pgid, signal.SIGTERM) if own_group else proc.terminate()
+        except ProcessLookupError:
+            return
+        try:
+            proc.wait(timeout=grace)
+        except subprocess.TimeoutExpired:
+            pass
+        try:
+            os.killpg(pgid, signal.SIGKILL) if own_group else proc.kill()   # stragglers of the group, if any
+        except ProcessLookupError:
+            pass
 
     # ---- metadata (replaces the ffprobe call, app/vmaf_analyzer.py:162-240) -------------------------
     def get_video_metadata(self, video_path, ffprobe_exe=None):
@@ -300,6 +325,10 @@ class VMAFAnalyzer(QObject):
                "--n-subsample", str(max(1, int(self.feature_subsample or 1))), "--batch", str(self.max_batch)]
         if self.fixed_point:
             cmd += ["--fixed-point", str(int(self.fixed_point))]
+        if self.child_backend != "nccl":
+            cmd += ["--backend", self.child_backend]
+        if self.child_share_device:
+            cmd += ["--share-device"]
         if psnr_path:
             cmd += ["--psnr-log", psnr_path]
         if ssim_path:
@@ -312,7 +341,7 @@ class VMAFAnalyzer(QObject):
         stderr_lines = []
         try:
             self._current_process = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
-                                                     bufsize=1, env=env)
+                                                     bufsize=1, env=env, start_new_session=True)
             for line in iter(self._current_process.stderr.readline, ""):
                 if self._terminate_requested:
                     break
@@ -330,7 +359,7 @@ class VMAFAnalyzer(QObject):
         finally:
             proc, self._current_process = self._current_process, None
             if proc is not None and proc.poll() is None:
-                proc.kill()
+                self._stop_child(proc, grace=1.0)
         if self._terminate_requested:
             self._fail("VMAF analysis was terminated by user")
             return False

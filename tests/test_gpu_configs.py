@@ -1,0 +1,340 @@
+"""BASELINE.json configs at FULL size under the driver's `-m gpu` run (VERDICT r1 "configs not exercised"):
+
+  configs[2]  2160p 8-bit  vmaf_4k_v0.6.1          -> one frame pair against the oracle
+  configs[4]  2160p 10-bit vmaf_v0.6.1neg + PSNR + SSIM on all planes (4:2:0)
+              -> size-independent properties + one frame pair against the oracle (u16 kernels at 4K)
+
+plus the C-ABI call-sequence promises of include/pqa_vmaf.h (PQA_ESTATE) and piecewise collection
+while later batches are still running.  Tolerances as in test_gpu_parity.py: features 5e-5 relative
+(f32 kernels vs the f32 restatement), SSE bit-exact, SSIM 1e-9, VMAF 0.01.
+"""
+import numpy as np
+import pytest
+
+from pqa2_amd import model as M
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 5e-5
+VMAF_TOL = 0.01
+W4K, H4K = 3840, 2160
+
+
+def _planes_host(clip, key, i, bpc):
+    out = []
+    for t in clip[key]:
+        a = t[i].cpu().numpy()
+        out.append(a.view(np.uint16) if bpc > 8 else a)
+    return out
+
+
+def _resident_args(clip, key, es):
+    ts = clip[key]
+    return ([t.data_ptr() for t in ts], [t.shape[2] * es for t in ts], [t.shape[1] * t.shape[2] * es for t in ts])
+
+
+def test_config_2160p_8bit_frame_pair_against_oracle(oracle32):
+    """BASELINE configs[2]: 3840x2160 8-bit, vmaf_4k_v0.6.1 (integer border), two frames vs the oracle."""
+    import torch
+    from pqa2_amd import synth_torch
+    from pqa2_amd.engine import FeatureEngine
+    mdl = M.load_model("vmaf_4k_v0.6.1")
+    n = 2
+    clip = synth_torch.make_clip_cuda(W4K, H4K, n, 8, device="cuda")
+    torch.cuda.synchronize()
+    rp, rpitch, fpitch = _resident_args(clip, "ref", 1)
+    dp, _, _ = _resident_args(clip, "dis", 1)
+    with FeatureEngine(W4K, H4K, vif_border=mdl.vif_border, vif_enhn_gain_limit=mdl.vif_enhn_gain_limit,
+                       adm_enhn_gain_limit=mdl.adm_enhn_gain_limit) as eng:
+        eng.submit_resident(0, n, rp, dp, rpitch, fpitch)
+        got = eng.collect(0, n)
+    refs = [_planes_host(clip, "ref", i, 8)[0] for i in range(n)]
+    diss = [_planes_host(clip, "dis", i, 8)[0] for i in range(n)]
+    exp = oracle32.clip_features_mt(refs, diss, 8, 2, vif_border101=bool(mdl.vif_border))
+    rel = np.abs(got[:, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-12)
+    assert rel.max() < REL_TOL, rel.max()
+    assert abs(got[1, 16] - exp[1, 16]) < 5e-6 * exp[1, 16] + 2e-5 and got[0, 16] == 0.0
+    rec = np.zeros((n, 24)); rec[:, :17] = exp
+    v_exp = M.score_frames(mdl, M.metrics_from_records(rec, W4K, H4K, "integer_"))["vmaf"]
+    v_got = M.score_frames(mdl, M.metrics_from_records(got, W4K, H4K, "integer_"))["vmaf"]
+    assert np.abs(v_exp - v_got).max() <= VMAF_TOL
+
+
+def test_config_2160p_10bit_neg_psnr_ssim_all_planes(oracle32):
+    """BASELINE configs[4]: 3840x2160 10-bit 4:2:0, vmaf_v0.6.1neg (both gain limits 1.0, models/vmaf_v0.6.1neg.json
+    :34-51), PSNR + SSIM on Y, U, V.  Properties at full size, then two frames against the oracle."""
+    import torch
+    from pqa2_amd import _native as N
+    from pqa2_amd import synth_torch
+    from pqa2_amd.engine import FeatureEngine, sse_from_records
+    mdl = M.load_model("vmaf_v0.6.1neg")
+    assert mdl.vif_enhn_gain_limit == 1.0 and mdl.adm_enhn_gain_limit == 1.0
+    bpc, es, n = 10, 2, 3
+    w, h = W4K, H4K
+    cw, ch = w // 2, h // 2
+    clip = synth_torch.make_clip_cuda(w, h, n, bpc, device="cuda", chroma=True)
+    torch.cuda.synchronize()
+    rp, rpitch, fpitch = _resident_args(clip, "ref", es)
+    dp, _, _ = _resident_args(clip, "dis", es)
+    kw = dict(bit_depth=bpc, n_planes=3, features=N.FEAT_ALL, vif_border=mdl.vif_border,
+              vif_enhn_gain_limit=1.0, adm_enhn_gain_limit=1.0)
+    with FeatureEngine(w, h, max_batch=2, **kw) as eng:
+        eng.submit_resident(0, n, rp, rp, rpitch, fpitch)                      # identical
+        ident = eng.collect(0, n)
+        eng.reset()
+        eng.submit_resident(0, n, rp, dp, rpitch, fpitch)                      # the real pair
+        pair = eng.collect(0, n)
+        static = [t[:1].expand(n, *t.shape[1:]).contiguous() for t in clip["ref"]]
+        sp = [t.data_ptr() for t in static]
+        eng.reset()
+        eng.submit_resident(0, n, sp, sp, rpitch, fpitch)                      # static
+        stat = eng.collect(0, n)
+        c = 5
+        lo = [t.to(torch.int32).clamp(0, 1023 - c).to(torch.int16) for t in clip["ref"]]
+        hi = [(t.to(torch.int32) + c).to(torch.int16) for t in lo]
+        eng.reset()
+        eng.submit_resident(0, n, [t.data_ptr() for t in lo], [t.data_ptr() for t in hi], rpitch, fpitch)
+        off = eng.collect(0, n)
+    np.testing.assert_allclose(ident[:, 0:4] / ident[:, 4:8], 1.0, atol=2e-5)
+    np.testing.assert_allclose(ident[:, 8:12] / ident[:, 12:16], 1.0, atol=1e-6)
+    assert np.all(sse_from_records(ident) == 0) and np.allclose(ident[:, 17:20], 1.0)
+    assert np.all(stat[:, 16] == 0.0) and pair[0, 16] == 0.0 and np.all(pair[1:, 16] > 0)
+    want_sse = np.array([c * c * w * h, c * c * cw * ch, c * c * cw * ch], np.uint64)
+    assert np.all(sse_from_records(off) == want_sse[None, :])
+    # the neg model's gain limit: a contrast-enhanced copy may not score above the reference itself
+    assert np.all(pair[:, 0:4] <= pair[:, 4:8] * (1 + 1e-6))
+    # host path over the same bytes == resident path, bit for bit (u16 staging, three planes, 2160p)
+    with FeatureEngine(w, h, max_batch=3, **kw) as eng:
+        for i in range(n):
+            eng.submit(i, _planes_host(clip, "ref", i, bpc), _planes_host(clip, "dis", i, bpc))
+        host = eng.collect(0, n)
+    assert np.array_equal(host.view(np.uint64), pair.view(np.uint64))
+    # two frames against the oracle: u16 VIF / ADM / motion at 4K, SSE exact, SSIM of all planes
+    m = 2
+    refs = [_planes_host(clip, "ref", i, bpc) for i in range(m)]
+    diss = [_planes_host(clip, "dis", i, bpc) for i in range(m)]
+    exp = oracle32.clip_features_mt([r[0] for r in refs], [d[0] for d in diss], bpc, 2, vif_gain_limit=1.0,
+                                    adm_gain_limit=1.0, vif_border101=bool(mdl.vif_border))
+    rel = np.abs(pair[:m, :16] - exp[:, :16]) / np.maximum(np.abs(exp[:, :16]), 1e-12)
+    assert rel.max() < REL_TOL, rel.max()
+    assert abs(pair[1, 16] - exp[1, 16]) < 5e-6 * exp[1, 16] + 2e-5
+    sse = sse_from_records(pair)
+    for i in range(m):
+        for p in range(3):
+            assert int(sse[i, p]) == oracle32.sse_plane(diss[i][p], refs[i][p], bpc)
+            assert abs(pair[i, 17 + p] - oracle32.ssim_plane(diss[i][p], refs[i][p], bpc)) < 1e-9
+    rec = np.zeros((m, 24)); rec[:, :17] = exp
+    v_exp = M.score_frames(mdl, M.metrics_from_records(rec, w, h, "integer_"))["vmaf"]
+    v_got = M.score_frames(mdl, M.metrics_from_records(pair[:m], w, h, "integer_"))["vmaf"]
+    assert np.abs(v_exp - v_got).max() <= VMAF_TOL
+
+
+# ---- C-ABI call-sequence promises (include/pqa_vmaf.h: PQA_ESTATE) ---------------------------------------------
+def _small_clip(n, w=96, h=64):
+    from pqa2_amd import synth
+    return synth.make_clip(w, h, n, 8, chroma=False)
+
+
+def test_collect_of_a_never_submitted_frame_is_estate():
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import FeatureEngine
+    refs, diss = _small_clip(3)
+    with FeatureEngine(96, 64, max_batch=2, result_capacity=8) as eng:
+        with pytest.raises(N.PqaError) as e:
+            eng.collect(0, 1)                       # nothing submitted at all
+        assert e.value.code == N.PQA_ESTATE and "never submitted" in str(e.value)
+        for i in range(3):
+            eng.submit(i, refs[i], diss[i])
+        with pytest.raises(N.PqaError) as e:
+            eng.collect(2, 2)                       # frame 3 was never submitted
+        assert e.value.code == N.PQA_ESTATE
+        assert eng.collect(0, 3).shape == (3, 24)   # the context is still usable
+        eng.reset()
+        with pytest.raises(N.PqaError) as e:        # reset starts a new clip: old records are gone
+            eng.collect(0, 1)
+        assert e.value.code == N.PQA_ESTATE
+
+
+def test_overwriting_an_uncollected_record_is_estate():
+    import torch
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import FeatureEngine
+    n, w, h = 6, 96, 64
+    refs, diss = _small_clip(n, w, h)
+    with FeatureEngine(w, h, max_batch=2, result_capacity=4) as eng:    # ring of 4 records
+        for i in range(4):
+            eng.submit(i, refs[i], diss[i])
+        with pytest.raises(N.PqaError) as e:
+            eng.submit(4, refs[4], diss[4])         # slot 0 still holds the uncollected record of frame 0
+        assert e.value.code == N.PQA_ESTATE and "uncollected" in str(e.value)
+        first = eng.collect(0, 2)                   # frees slots 0 and 1
+        eng.submit(4, refs[4], diss[4])
+        eng.submit(5, refs[5], diss[5])
+        rest = eng.collect(2, 4)
+        with pytest.raises(N.PqaError) as e:        # frame 0's record has been replaced by frame 4's
+            eng.collect(0, 1)
+        assert e.value.code == N.PQA_ESTATE
+        eng.submit(1, refs[1], diss[1])             # the SAME index again (a re-run) is not an overwrite
+    with FeatureEngine(w, h, max_batch=4, result_capacity=16) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        full = eng.collect(0, n)
+    assert np.array_equal(np.concatenate([first, rest]).view(np.uint64), full.view(np.uint64))
+    # device-resident submit: the same rule, checked per batch before anything is launched
+    R = torch.from_numpy(np.stack([r[0] for r in refs])).cuda()
+    D = torch.from_numpy(np.stack([d[0] for d in diss])).cuda()
+    with FeatureEngine(w, h, max_batch=2, result_capacity=4) as eng:
+        eng.submit_resident(0, 4, [R.data_ptr()], [D.data_ptr()], [w], [w * h])
+        with pytest.raises(N.PqaError) as e:
+            eng.submit_resident(4, 2, [R[4:].data_ptr()], [D[4:].data_ptr()], [w], [w * h], R[3].data_ptr(), w)
+        assert e.value.code == N.PQA_ESTATE
+        got = eng.collect(0, 4)
+        eng.submit_resident(4, 2, [R[4:].data_ptr()], [D[4:].data_ptr()], [w], [w * h], R[3].data_ptr(), w)
+        got = np.concatenate([got, eng.collect(4, 2)])
+    assert np.array_equal(got.view(np.uint64), full.view(np.uint64))
+
+
+def test_piecewise_collect_while_later_batches_run():
+    """pqa_collect(first, count) waits for the batch that produced those records only (per-batch events): collecting
+    batch by batch while the rest of a 1080p clip is still in flight returns exactly the records of one final collect."""
+    import torch
+    from pqa2_amd import synth_torch
+    from pqa2_amd.engine import FeatureEngine
+    w, h, n, B = 1920, 1080, 24, 4
+    clip = synth_torch.make_clip_cuda(w, h, n, 8, device="cuda")
+    torch.cuda.synchronize()
+    rp, rpitch, fpitch = _resident_args(clip, "ref", 1)
+    dp, _, _ = _resident_args(clip, "dis", 1)
+    with FeatureEngine(w, h, max_batch=B) as eng:
+        eng.submit_resident(0, n, rp, dp, rpitch, fpitch)
+        whole = eng.collect(0, n)
+        eng.reset()
+        eng.submit_resident(0, n, rp, dp, rpitch, fpitch)
+        parts = [eng.collect(i, B) for i in range(0, n, B)]          # in order, each waits for its own batch
+        eng.reset()
+        eng.submit_resident(0, n, rp, dp, rpitch, fpitch)
+        back = [eng.collect(i, B) for i in range(n - B, -1, -B)][::-1]  # youngest first: waits for everything at once
+    assert np.array_equal(np.concatenate(parts).view(np.uint64), whole.view(np.uint64))
+    assert np.array_equal(np.concatenate(back).view(np.uint64), whole.view(np.uint64))
+
+
+# ---- the N > 1 path with the REAL engine -------------------------------------------------------
+def _write_pair(tmp_path, w, h, n, bpc=8):
+    from pqa2_amd import synth, yuvio
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=True)
+    info = synth.clip_info(w, h, bpc)
+    rp, dp = str(tmp_path / "ref.y4m"), str(tmp_path / "dist.y4m")
+    yuvio.write_y4m(rp, refs, info)
+    yuvio.write_y4m(dp, diss, info)
+    return rp, dp
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _strip_fps(path):
+    import json
+    d = json.load(open(path))
+    d.pop("fps", None)       # wall-clock: the only field that legitimately differs between runs
+    return json.dumps(d, sort_keys=True)
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_torchrun_ranks_share_the_gpu_and_match_single_process(tmp_path, ranks):
+    """python -m torch.distributed.run --nproc-per-node N -m pqa2_amd.score: N fresh processes, each with its own
+    pqa_ctx on the HIP engine (frame shard + one-frame motion halo through pqa_set_motion_halo), records all-gathered
+    (gloo here: the ranks share this box's single GPU; RCCL needs one GPU per rank), rank 0 writes JSON + stats files.
+    Everything but the wall-clock `fps` field must equal the single-process run byte for byte."""
+    import os
+    import subprocess
+    import sys
+    w, h, n = 320, 180, 11        # 11 frames over 2 / 3 ranks: uneven shards, seams at odd positions
+    rp, dp = _write_pair(tmp_path, w, h, n)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for tag, launcher in (("one", []), ("many", ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+                                                  "--master-addr", "127.0.0.1", "--master-port", str(_free_port())])):
+        j, ps, ss = (str(tmp_path / f"{tag}.{x}") for x in ("json", "psnr", "ssim"))
+        cmd = [sys.executable] + launcher + ["-m", "pqa2_amd.score", rp, dp, "--json", j, "--psnr-log", ps, "--ssim-log", ss,
+                                            "--model", "vmaf_v0.6.1", "--batch", "2"]
+        if launcher:
+            cmd += ["--backend", "gloo", "--share-device"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = (j, ps, ss)
+    assert _strip_fps(outs["one"][0]) == _strip_fps(outs["many"][0])
+    for k in (1, 2):
+        assert open(outs["one"][k]).read() == open(outs["many"][k]).read()
+
+
+def test_analyzer_gpus2_child_job_on_one_gpu(tmp_path):
+    """VMAFAnalyzer.gpus = 2 end to end (torchrun child with two ranks, progress lines, result dict), rehearsed on this
+    one-GPU box with child_backend = gloo + child_share_device; same numbers as the in-process run."""
+    from pqa2_amd import VMAFAnalyzer
+    rp, dp = _write_pair(tmp_path, 256, 144, 9)
+    a = VMAFAnalyzer()
+    a.set_output_directory(str(tmp_path / "single"))
+    (tmp_path / "single").mkdir()
+    a.set_test_name("t")
+    errs = []
+    a.error_occurred.connect(errs.append)
+    one = a.analyze_videos(rp, dp, "vmaf_v0.6.1")
+    assert one is not None and errs == []
+    b = VMAFAnalyzer()
+    (tmp_path / "double").mkdir()
+    b.set_output_directory(str(tmp_path / "double"))
+    b.set_test_name("t")
+    b.gpus, b.child_backend, b.child_share_device = 2, "gloo", True
+    b.error_occurred.connect(errs.append)
+    two = b.analyze_videos(rp, dp, "vmaf_v0.6.1")
+    assert two is not None and errs == [], errs
+    assert two["vmaf_score"] == one["vmaf_score"]
+    assert [f["metrics"] for f in two["raw_results"]["frames"]] == [f["metrics"] for f in one["raw_results"]["frames"]]
+    assert open(two["psnr_log"]).read() == open(one["psnr_log"]).read()
+    assert open(two["ssim_log"]).read() == open(one["ssim_log"]).read()
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+from pqa2_amd import shard, synth
+from pqa2_amd.engine import FeatureEngine
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{sys.argv[1]}", world_size=1, rank=0, device_id=dev)
+w, h, n = 192, 108, 5
+refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+with FeatureEngine(w, h, max_batch=2) as eng:
+    for i in range(n):
+        eng.submit(i, refs[i], diss[i])
+    local = eng.collect(0, n)
+local[:, 20] = np.array([2**63 + 12345, 1, 0, 2**64 - 1, 7], np.uint64).view(np.float64)   # NaN-pattern payloads
+full = shard.gather_records(local, n, 1, 0, dev, force_collective=True)      # all_gather_into_tensor on the GPU: RCCL
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                                      # bench.py's max-over-ranks timing call
+dist.barrier()
+dist.destroy_process_group()
+assert np.array_equal(full.view(np.uint64), local.view(np.uint64)), "records changed in the RCCL gather"
+assert float(t.item()) == 1.5
+print("rccl-one-rank ok")
+"""
+
+
+def test_rccl_gather_of_device_records_with_one_rank(tmp_path):
+    """init_process_group("nccl") (= RCCL), the int64 all_gather_into_tensor of shard.gather_records on a DEVICE tensor,
+    bench.py's all_reduce(MAX) and barrier -- with the one rank this box can host.  More ranks need more GPUs: the
+    driver's 8-GPU SCALE run is the only place RCCL carries data between devices."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, str(_free_port())], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "rccl-one-rank ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
