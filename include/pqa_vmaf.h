@@ -183,6 +183,13 @@ PQA_API const char* pqa_last_error(const pqa_ctx* ctx);
 PQA_API int pqa_luma_stats_device(pqa_ctx* ctx, const void* luma, int64_t row_pitch, int64_t frame_pitch,
                                   int32_t n_frames, uint32_t threshold, uint64_t* out);
 
+/* The same statistics for frames in HOST memory: luma_frames[i] points at frame i's luma plane (rows row_stride bytes
+ * apart; the frames need not be contiguous -- a detector samples every k-th frame of a memory-mapped clip).  Frames
+ * are packed into pinned staging and uploaded in chunks while the previous chunk's kernel runs.  out[n_frames][3] as
+ * above.  This is what pqa2_amd.bookend.detect() drives.  Synchronous. */
+PQA_API int pqa_luma_stats(pqa_ctx* ctx, const void* const* luma_frames, int64_t row_stride, int32_t n_frames,
+                           uint32_t threshold, uint64_t* out);
+
 /* Measurement hooks (bench.py): HIP-event timing of individual kernels on the context's stream.
  * kernel ids: 0..3 vif_stat scale s (each also produces the next scale's planes), 4..6 reserved,
  * 7..10 adm scale s,

@@ -23,7 +23,7 @@ PROF_KERNELS = 15
 EXPORTS = [
     "pqa_version", "pqa_record_doubles", "pqa_config_init", "pqa_create", "pqa_destroy", "pqa_set_stream",
     "pqa_submit", "pqa_submit_device", "pqa_set_motion_halo", "pqa_flush", "pqa_collect", "pqa_sync",
-    "pqa_cancel", "pqa_reset", "pqa_last_error", "pqa_luma_stats_device", "pqa_profile_enable",
+    "pqa_cancel", "pqa_reset", "pqa_last_error", "pqa_luma_stats_device", "pqa_luma_stats", "pqa_profile_enable",
     "pqa_profile_read", "pqa_profile_kernel_name",
 ]
 
@@ -106,6 +106,7 @@ def load():
     lib.pqa_sync.argtypes = [vp]
     lib.pqa_cancel.argtypes = [vp]
     lib.pqa_luma_stats_device.argtypes = [vp, vp, i64, i64, i32, C.c_uint32, vp]
+    lib.pqa_luma_stats.argtypes = [vp, C.POINTER(vp), i64, i32, C.c_uint32, vp]
     lib.pqa_reset.argtypes = [vp]
     lib.pqa_last_error.argtypes = [vp]
     lib.pqa_last_error.restype = C.c_char_p

@@ -45,3 +45,178 @@ def starts_with_bookend(white_ratio_at_200, max_frames: int = 30) -> bool:
     """app/reference_analyzer.py:124-144: any of the first 30 frames with > 85 % of pixels above 200."""
     r = np.asarray(white_ratio_at_200)[:max_frames]
     return bool(np.any(r > 0.85))
+
+
+# ---- the detector: coarse scan -> regions -> frame-accurate scan (app/bookend_alignment.py:755-1133) -----------------
+def numpy_stats_fn(reader):
+    """CPU stand-in for the GPU reduction, for tests: the same three exact integers from numpy."""
+    def fn(indices, threshold):
+        out = np.zeros((len(indices), 3), np.uint64)
+        for k, i in enumerate(indices):
+            y = np.asarray(reader.frame(int(i))[0]).astype(np.uint64)
+            out[k] = (y.sum(), (y * y).sum(), (y > np.uint64(threshold)).sum())
+        return out
+    return fn
+
+
+def engine_stats_fn(reader, engine, chunk: int = 64):
+    """Frames of `reader` -> FeatureEngine.luma_stats (pqa_luma_stats: pack, upload, one streaming HIP reduction)."""
+    def fn(indices, threshold):
+        parts = []
+        for a in range(0, len(indices), chunk):
+            frames = [reader.frame(int(i))[0] for i in indices[a:a + chunk]]
+            parts.append(engine.luma_stats(frames, threshold))
+        return np.concatenate(parts) if parts else np.zeros((0, 3), np.uint64)
+    return fn
+
+
+def detect(reader, engine=None, *, frame_sampling_rate: float = 5, adaptive_brightness: bool = True,
+           white_threshold: float = 230, fallback_to_full_video: bool = True, stats_fn=None):
+    """White bookend sections of a clip, the reference's `_detect_white_bookends` (app/bookend_alignment.py:755-1133)
+    on exact GPU reductions: returns the list of dicts {start_frame, end_frame, start_time, end_time, frame_count,
+    brightness, std_dev[, is_fallback]} sorted by start_frame (the caller pairs first/last like the reference does).
+
+    `reader`: a pqa2_amd.yuvio reader (len, .frame(i) -> planes, .info).  `engine`: a FeatureEngine of the clip's
+    geometry (its pqa_luma_stats does the reductions); or pass `stats_fn(indices, int_threshold) -> [n,3] uint64`.
+    Gray is the luma plane, in 8-bit units (deeper samples are scaled down by 2^(bpc-8), the count threshold up).
+    Differences from the reference, none of which changes a decision: the per-frame (mean, std) of the coarse pass
+    are computed once and reused for all three thresholds (the reference re-decodes the clip per threshold); frames are
+    fetched by index instead of cv2 seeks."""
+    info = reader.info
+    fps = float(info.fps)
+    frame_count = len(reader)
+    if frame_count <= 0 or fps <= 0:
+        return None
+    duration = frame_count / fps
+    n_pixels = info.width * info.height
+    scale = float(1 << (info.bit_depth - 8))
+    if stats_fn is None:
+        if engine is None:
+            raise ValueError("detect() needs a FeatureEngine (the reductions run on the GPU) or a stats_fn")
+        stats_fn = engine_stats_fn(reader, engine)
+
+    def brightness(indices, threshold8=255.0):
+        thr = int(np.floor(max(0.0, float(threshold8)) * scale))   # gray > t  <=>  integer sample > floor(t * scale)
+        st = stats_fn(list(indices), thr)
+        mean, std, ratio = brightness_from_stats(st, n_pixels)
+        return mean / scale, std / scale, ratio
+
+    # 1. brightness samples across the clip (:775-805)
+    sample_interval = max(1, int(fps / frame_sampling_rate))
+    sample_idx = list(range(0, frame_count, sample_interval))
+    s_mean, s_std, _ = brightness(sample_idx)
+    if len(s_mean) == 0:
+        return None
+    avg_brightness, std_brightness = float(np.mean(s_mean)), float(np.std(s_mean))
+    max_brightness, avg_std_dev = float(np.max(s_mean)), float(np.mean(s_std))
+
+    # 2. thresholds (:818-852)
+    if adaptive_brightness:
+        dynamic = max(avg_brightness + 2.0 * std_brightness, max_brightness * 0.85, 180)
+        if max_brightness > 240:
+            dynamic = max(dynamic, 220)
+        elif max_brightness < 200:
+            dynamic = max(avg_brightness + 1.5 * std_brightness, 160)
+        thresholds = [dynamic, dynamic * 0.9, max(avg_brightness + 20, 160)]
+    else:
+        thresholds = [white_threshold, white_threshold * 0.9, white_threshold * 0.8]
+
+    min_white_frames = max(3, int(0.1 * fps)) if fps > 25 else 3          # :871-874
+    initial_sample_rate = max(3, int(fps // 8))                           # :879
+    std_dev_threshold = min(45, avg_std_dev * 1.8)                        # :882
+
+    # 3. coarse pass (:885-935): one set of reductions, three threshold sweeps over it
+    coarse_idx = list(range(0, frame_count, initial_sample_rate))
+    c_mean, c_std, _ = brightness(coarse_idx)
+    regions = []
+    for t_idx, thr in enumerate(thresholds):
+        white = is_white_initial(c_mean, c_std, thr, std_dev_threshold, t_idx)
+        potential, cur = [], None
+        frame_idx = 0
+        for k, frame_idx in enumerate(coarse_idx):
+            if white[k]:
+                if cur is None:
+                    cur = {"start_frame": max(0, frame_idx - initial_sample_rate), "brightness": float(c_mean[k])}
+            elif cur is not None:
+                cur["end_frame"] = min(frame_count - 1, frame_idx + initial_sample_rate)
+                potential.append(cur)
+                cur = None
+        if cur is not None:
+            cur["end_frame"] = min(frame_count - 1, frame_idx + initial_sample_rate)
+            potential.append(cur)
+        for r in potential:
+            regions.append((max(0, r["start_frame"] - initial_sample_rate),
+                            min(frame_count - 1, r["end_frame"] + initial_sample_rate), thr))
+    if not regions:
+        regions = [(0, frame_count - 1, thresholds[-1])]                  # :938-940
+    if len(regions) > 1:                                                  # merge overlaps (:943-957)
+        regions.sort()
+        merged = []
+        cs, ce, ct = regions[0]
+        for s, e, t in regions[1:]:
+            if s <= ce:
+                ce, ct = max(ce, e), min(ct, t)
+            else:
+                merged.append((cs, ce, ct))
+                cs, ce, ct = s, e, t
+        merged.append((cs, ce, ct))
+        regions = merged
+
+    # 4. frame-accurate pass (:964-1063)
+    all_bookends = []
+    for start, end, thr in regions:
+        if end - start < min_white_frames:
+            continue
+        idx = list(range(start, end + 1))
+        mean, std, ratio = brightness(idx, thr)
+        white = is_white_refined(mean, std, ratio, thr, std_dev_threshold)
+        run, cur = 0, None
+        for k, f in enumerate(idx):
+            if white[k]:
+                run += 1
+                if cur is None:
+                    cur = {"start_frame": f, "start_time": f / fps, "frame_count": 1,
+                           "brightness": float(mean[k]), "std_dev": float(std[k])}
+            elif cur is not None:
+                cur["end_frame"], cur["end_time"], cur["frame_count"] = f - 1, (f - 1) / fps, run
+                if run >= min_white_frames:
+                    all_bookends.append(cur)
+                cur, run = None, 0
+        if cur is not None and run >= min_white_frames:
+            cur["end_frame"], cur["end_time"], cur["frame_count"] = end, end / fps, run
+            all_bookends.append(cur)
+
+    # 5. de-duplicate, sort, fall back (:1066-1128)
+    unique = []
+    for b in all_bookends:
+        dup = False
+        for e in unique:
+            if b["start_frame"] <= e["end_frame"] and b["end_frame"] >= e["start_frame"]:
+                if b["frame_count"] > e["frame_count"] or b["brightness"] > e["brightness"]:
+                    unique.remove(e)
+                    unique.append(b)
+                dup = True
+                break
+        if not dup:
+            unique.append(b)
+    bookends = sorted(unique, key=lambda x: x["start_frame"])
+    if len(bookends) < 2 and fallback_to_full_video:
+        bookends = [
+            {"start_frame": 0, "end_frame": min(5, frame_count - 1), "start_time": 0, "end_time": min(5, frame_count - 1) / fps,
+             "frame_count": min(5, frame_count), "brightness": 0, "std_dev": 0, "is_fallback": True},
+            {"start_frame": max(0, frame_count - 5), "end_frame": frame_count - 1, "start_time": max(0, frame_count - 5) / fps,
+             "end_time": duration, "frame_count": min(5, frame_count), "brightness": 0, "std_dev": 0, "is_fallback": True},
+        ]
+    return bookends
+
+
+def content_span(bookends, fps: float):
+    """First/last bookend pairing of the aligner (app/bookend_alignment.py:324-345): the content lies between the end of
+    the first white section and the start of the last one, with a 1.5-frame buffer on both sides.  Returns
+    (content_start_time, content_end_time) in seconds, or None when the timing is invalid."""
+    if not bookends or len(bookends) < 2 or fps <= 0:
+        return None
+    first, last = bookends[0], bookends[-1]
+    buf = 1.5 / fps
+    a, b = first["end_time"] + buf, last["start_time"] - buf
+    return (a, b) if b > a else None

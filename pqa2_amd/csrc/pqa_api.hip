@@ -165,6 +165,12 @@ struct pqa_ctx {
   double* records = nullptr;
   unsigned long long* luma_part = nullptr;
   unsigned long long* luma_out = nullptr;
+  // host-frame luma statistics (pqa_luma_stats): two pinned + two device halves of LB luma planes
+  uint8_t* luma_pinned[2] = {nullptr, nullptr};
+  uint8_t* luma_dev[2] = {nullptr, nullptr};
+  hipEvent_t luma_copied[2] = {nullptr, nullptr};
+  int64_t luma_pitch = 0;
+  int LB = 0;
   // motion continuity
   uint8_t* last_luma = nullptr;
   int64_t last_luma_pitch = 0;  // bytes
@@ -837,6 +843,11 @@ void pqa_destroy(pqa_ctx* c) {
     if (H.copied) hipEventDestroy(H.copied);
     if (H.computed) hipEventDestroy(H.computed);
   }
+  for (int i = 0; i < 2; ++i) {
+    if (c->luma_pinned[i]) hipHostFree(c->luma_pinned[i]);
+    if (c->luma_dev[i]) hipFree(c->luma_dev[i]);
+    if (c->luma_copied[i]) hipEventDestroy(c->luma_copied[i]);
+  }
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   for (int i = 0; i < 2; ++i) {
     if (c->aux[i]) hipStreamDestroy(c->aux[i]);
@@ -1090,6 +1101,50 @@ int pqa_luma_stats_device(pqa_ctx* c, const void* luma, int64_t row_pitch, int64
     HIPCHK(c, hipStreamSynchronize(c->stream));
     done += n;
   }
+  return PQA_OK;
+}
+
+int pqa_luma_stats(pqa_ctx* c, const void* const* luma_frames, int64_t row_stride, int32_t n_frames, uint32_t threshold,
+                   uint64_t* out) {
+  if (!c) return PQA_EINVAL;
+  if (n_frames < 0 || (n_frames > 0 && (!luma_frames || !out))) return fail(c, PQA_EINVAL, "bad argument");
+  const size_t row_bytes = (size_t)c->pw[0] * c->esize;
+  if (n_frames > 0 && (size_t)row_stride < row_bytes) return fail(c, PQA_EINVAL, "stride smaller than a row");
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int h = c->ph[0];
+  if (!c->luma_pinned[0]) {  // lazily: most contexts never detect bookends
+    c->luma_pitch = round_up((int64_t)row_bytes, 64);
+    c->LB = c->B < 8 ? c->B : 8;
+    const size_t half = (size_t)c->luma_pitch * h * c->LB;
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(c, hipHostMalloc((void**)&c->luma_pinned[i], half, hipHostMallocDefault));
+      HIPCHK(c, hipMalloc((void**)&c->luma_dev[i], half));
+      HIPCHK(c, hipEventCreateWithFlags(&c->luma_copied[i], hipEventDisableTiming));
+    }
+  }
+  const size_t frame_bytes = (size_t)c->luma_pitch * h;
+  int chunk = 0;
+  for (int done = 0; done < n_frames; ++chunk) {
+    if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+    const int n = n_frames - done < c->LB ? n_frames - done : c->LB;
+    const int hf = chunk & 1;
+    if (chunk >= 2) HIPCHK(c, hipEventSynchronize(c->luma_copied[hf]));  // the upload two chunks ago has left this half
+    for (int f = 0; f < n; ++f) {
+      if (!luma_frames[done + f]) return fail(c, PQA_EINVAL, "frame %d pointer is null", done + f);
+      copy_plane_rows(c->luma_pinned[hf] + (size_t)f * frame_bytes, c->luma_pitch, (const uint8_t*)luma_frames[done + f],
+                      row_stride, row_bytes, h);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->luma_dev[hf], c->luma_pinned[hf], (size_t)n * frame_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->luma_copied[hf], c->stream));
+    const PlaneRun run{c->luma_dev[hf], c->luma_pitch / c->esize, (int64_t)(frame_bytes / c->esize)};
+    HIPCHK(c, launch_luma_stats(c->stream, c->elem, run, n, c->pw[0], h, threshold, c->luma_part, c->luma_out));
+    // stream-ordered: this copy is queued before the next chunk's kernel rewrites luma_out
+    HIPCHK(c, hipMemcpyAsync(out + (size_t)done * 3, c->luma_out, (size_t)n * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                             c->stream));
+    done += n;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return PQA_OK;
 }
 

@@ -109,6 +109,30 @@ class FeatureEngine:
                                                    int(threshold), out.ctypes.data))
         return out
 
+    def luma_stats(self, luma_frames, threshold: int) -> np.ndarray:
+        """[n,3] uint64 {sum, sum of squares, count(sample > threshold)} for luma planes in HOST memory (a list of 2-D
+        arrays of this engine's dtype with one common row stride; they are packed and uploaded by the library)."""
+        n = len(luma_frames)
+        out = np.zeros((n, 3), np.uint64)
+        if n == 0:
+            return out
+        keep, ptrs = [], (C.c_void_p * n)()
+        stride = None
+        for i, f in enumerate(luma_frames):
+            a = np.asarray(f)
+            if a.dtype != self.dtype or a.strides[1] != a.itemsize or (stride is not None and a.strides[0] != stride):
+                a = np.ascontiguousarray(a, dtype=self.dtype)
+            if stride is None:
+                stride = a.strides[0]
+            if a.strides[0] != stride:   # the first frame had an odd stride: normalise everything
+                return self.luma_stats([np.ascontiguousarray(x, dtype=self.dtype) for x in luma_frames], threshold)
+            if a.shape != (self.height, self.width):
+                raise ValueError(f"luma frame {i} is {a.shape}, engine is {(self.height, self.width)}")
+            keep.append(a)
+            ptrs[i] = a.ctypes.data
+        self._check(self.lib.pqa_luma_stats(self._ctx, ptrs, stride, n, int(threshold), out.ctypes.data))
+        return out
+
     # -- results -----------------------------------------------------------------------------
     def collect(self, first_index: int, count: int) -> np.ndarray:
         out = np.zeros((count, N.RECORD_DOUBLES), np.float64)

@@ -20,7 +20,10 @@ from oracle.oracle import Oracle  # noqa: E402
 from pqa2_amd import model as M, synth  # noqa: E402
 
 CASES = [("c64x48_8", 64, 48, 8, 3), ("c176x144_8", 176, 144, 8, 3), ("c321x241_8", 321, 241, 8, 2),
-         ("c200x120_10", 200, 120, 10, 2)]
+         ("c200x120_10", 200, 120, 10, 2), ("c352x288_8", 352, 288, 8, 3)]
+# clips also committed as .y4m under clips/: the inputs of tools/compare_libvmaf_log.py (run ffmpeg+libvmaf on them
+# wherever one exists, diff its JSON log against every restatement here)
+Y4M_CASES = ("c64x48_8", "c352x288_8")
 
 
 def main():
@@ -46,6 +49,12 @@ def main():
         out["cases"][name] = {"w": w, "h": h, "bpc": bpc, "n": n, "input_sha256": sha.hexdigest(),
                               "records": rec.tolist(), "vmaf_v0.6.1": vm.tolist(), "sse": sse, "ssim": ssim,
                               "records_fixed_point": rec_fx.tolist()}
+        if name in Y4M_CASES:
+            from pqa2_amd import yuvio
+            os.makedirs(os.path.join(HERE, "clips"), exist_ok=True)
+            info = synth.clip_info(w, h, bpc)
+            yuvio.write_y4m(os.path.join(HERE, "clips", f"{name}_ref.y4m"), refs, info)
+            yuvio.write_y4m(os.path.join(HERE, "clips", f"{name}_dist.y4m"), diss, info)
         if name == "c64x48_8":  # ship the actual bytes of the smallest case
             np.savez_compressed(os.path.join(HERE, "c64x48_8_frames.npz"),
                                 **{f"ref{i}_{p}": refs[i][p] for i in range(n) for p in range(3)},

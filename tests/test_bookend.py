@@ -1,0 +1,208 @@
+"""White bookend detection: pqa2_amd.bookend.detect against a test-side sequential loop that
+follows the reference's _detect_white_bookends statement by statement (app/bookend_alignment.py:755-1133) with
+np.mean / np.std / np.sum(gray > t) per frame -- the cv2 loops the GPU reduction replaces.  The CPU tests drive detect()
+with numpy reductions; the GPU test drives it through pqa_luma_stats (host frames -> pinned staging -> HIP kernel)."""
+import numpy as np
+import pytest
+
+from pqa2_amd import bookend, synth, yuvio
+
+
+def _clip_with_bookends(tmp_path, w, h, n, fps, white_runs, bpc=8, white_level=250, seed=3, partial=None):
+    """n frames of moving content; frames inside white_runs are white (level + a little noise); `partial` = (frame,
+    fraction) makes one frame only partly white (exercises the white-ratio rule)."""
+    rng = np.random.default_rng(seed)
+    scale = 1 << (bpc - 8)
+    frames = []
+    for t in range(n):
+        y = synth.ref_luma(w, h, t) * 0.8
+        for a, b in white_runs:
+            if a <= t <= b:
+                y = white_level + rng.normal(0, 1.0, (h, w))
+        if partial is not None and t == partial[0]:
+            y = y.copy()
+            y[: int(h * partial[1])] = white_level
+        y = np.clip(np.rint(y * scale), 0, (1 << bpc) - 1).astype(np.uint8 if bpc <= 8 else np.uint16)
+        frames.append([y])
+    info = synth.clip_info(w, h, bpc, chroma=False, fps=fps)
+    p = str(tmp_path / f"bookend_{bpc}.y4m")
+    yuvio.write_y4m(p, frames, info)
+    return p, frames
+
+
+def _reference_style_detect(frames, fps, bpc=8, frame_sampling_rate=5, adaptive=True, white_threshold=230, fallback=True):
+    """Sequential restatement of the reference loop: every decision from np.mean / np.std / np.sum(gray > t)."""
+    scale = float(1 << (bpc - 8))
+    gray_of = lambda i: frames[i][0].astype(np.float64) / scale
+    frame_count = len(frames)
+    duration = frame_count / fps
+    sample_interval = max(1, int(fps / frame_sampling_rate))
+    samples = [(i, np.mean(gray_of(i)), np.std(gray_of(i))) for i in range(0, frame_count, sample_interval)]
+    all_b = [b for _, b, _ in samples]
+    avg_b, std_b, max_b = np.mean(all_b), np.std(all_b), np.max(all_b)
+    avg_sd = np.mean([s for _, _, s in samples])
+    if adaptive:
+        dyn = max(avg_b + 2.0 * std_b, max_b * 0.85, 180)
+        if max_b > 240:
+            dyn = max(dyn, 220)
+        elif max_b < 200:
+            dyn = max(avg_b + 1.5 * std_b, 160)
+        thresholds = [dyn, dyn * 0.9, max(avg_b + 20, 160)]
+    else:
+        thresholds = [white_threshold, white_threshold * 0.9, white_threshold * 0.8]
+    min_white = max(3, int(0.1 * fps)) if fps > 25 else 3
+    isr = max(3, int(fps // 8))
+    sd_thr = min(45, avg_sd * 1.8)
+    roi = []
+    for ti, thr in enumerate(thresholds):
+        pot, cur = [], None
+        frame_idx = 0
+        for frame_idx in range(0, frame_count, isr):
+            g = gray_of(frame_idx)
+            m, s = np.mean(g), np.std(g)
+            white = m > thr if ti < 2 else (m > thr and s < sd_thr)
+            if white:
+                if cur is None:
+                    cur = {"start_frame": max(0, frame_idx - isr), "brightness": m}
+            elif cur is not None:
+                cur["end_frame"] = min(frame_count - 1, frame_idx + isr)
+                pot.append(cur)
+                cur = None
+        if cur is not None:
+            cur["end_frame"] = min(frame_count - 1, frame_idx + isr)
+            pot.append(cur)
+        for r in pot:
+            roi.append((max(0, r["start_frame"] - isr), min(frame_count - 1, r["end_frame"] + isr), thr))
+    if not roi:
+        roi = [(0, frame_count - 1, thresholds[-1])]
+    if len(roi) > 1:
+        roi.sort()
+        merged = []
+        cs, ce, ct = roi[0]
+        for s, e, t in roi[1:]:
+            if s <= ce:
+                ce, ct = max(ce, e), min(ct, t)
+            else:
+                merged.append((cs, ce, ct))
+                cs, ce, ct = s, e, t
+        merged.append((cs, ce, ct))
+        roi = merged
+    found = []
+    for s0, e0, thr in roi:
+        if e0 - s0 < min_white:
+            continue
+        run, cur = 0, None
+        for f in range(s0, e0 + 1):
+            g = gray_of(f)
+            m, s = np.mean(g), np.std(g)
+            white = False
+            if s < sd_thr * 1.2:
+                white = m > thr * 0.95
+            elif m > thr:
+                white = True
+            elif m > thr * 0.9:
+                white = np.sum(g > thr) / g.size > 0.7
+            if white:
+                run += 1
+                if cur is None:
+                    cur = {"start_frame": f, "start_time": f / fps, "frame_count": 1, "brightness": m, "std_dev": s}
+            elif cur is not None:
+                cur["end_frame"], cur["end_time"], cur["frame_count"] = f - 1, (f - 1) / fps, run
+                if run >= min_white:
+                    found.append(cur)
+                cur, run = None, 0
+        if cur is not None and run >= min_white:
+            cur["end_frame"], cur["end_time"], cur["frame_count"] = e0, e0 / fps, run
+            found.append(cur)
+    uniq = []
+    for b in found:
+        dup = False
+        for e in uniq:
+            if b["start_frame"] <= e["end_frame"] and b["end_frame"] >= e["start_frame"]:
+                if b["frame_count"] > e["frame_count"] or b["brightness"] > e["brightness"]:
+                    uniq.remove(e)
+                    uniq.append(b)
+                dup = True
+                break
+        if not dup:
+            uniq.append(b)
+    out = sorted(uniq, key=lambda x: x["start_frame"])
+    if len(out) < 2 and fallback:
+        out = [{"start_frame": 0, "end_frame": min(5, frame_count - 1), "is_fallback": True},
+               {"start_frame": max(0, frame_count - 5), "end_frame": frame_count - 1, "is_fallback": True}]
+    return out
+
+
+def _same(got, want):
+    assert len(got) == len(want), (got, want)
+    for g, w in zip(got, want):
+        assert (g["start_frame"], g["end_frame"]) == (w["start_frame"], w["end_frame"])
+        assert bool(g.get("is_fallback")) == bool(w.get("is_fallback"))
+        if not w.get("is_fallback"):
+            assert g["frame_count"] == w["frame_count"]
+            assert abs(g["brightness"] - w["brightness"]) < 1e-9 and abs(g["std_dev"] - w["std_dev"]) < 1e-7
+            assert abs(g["start_time"] - w["start_time"]) < 1e-12 and abs(g["end_time"] - w["end_time"]) < 1e-12
+
+
+CASES = [
+    # fps, n, white runs, kwargs
+    (30, 150, [(4, 12), (130, 141)], {}),
+    (30, 150, [(0, 9), (139, 149)], {}),                      # bookends touching both clip ends
+    (25, 120, [(10, 13), (60, 66), (100, 104)], {}),          # three sections, fps <= 25: 3-frame minimum
+    (60, 200, [(20, 31), (170, 181)], {"adaptive_brightness": False, "white_threshold": 230}),
+    (30, 90, [], {}),                                          # none: fallback pair
+    (30, 90, [(40, 41)], {"fallback_to_full_video": False}),   # a 2-frame flash is not a bookend, no fallback: []
+]
+
+
+@pytest.mark.parametrize("fps,n,runs,kw", CASES)
+def test_detect_matches_the_reference_style_loop(tmp_path, fps, n, runs, kw):
+    w, h = 96, 64
+    path, frames = _clip_with_bookends(tmp_path, w, h, n, fps, runs, partial=(runs[0][1] + 1, 0.8) if runs else None)
+    rd = yuvio.open_video(path)
+    got = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd), **kw)
+    want = _reference_style_detect(frames, fps, adaptive=kw.get("adaptive_brightness", True),
+                                   white_threshold=kw.get("white_threshold", 230),
+                                   fallback=kw.get("fallback_to_full_video", True))
+    _same(got, want)
+    if len(runs) >= 2:
+        assert got[0]["start_frame"] == runs[0][0] and got[-1]["end_frame"] == runs[-1][1]
+        span = bookend.content_span(got, fps)
+        assert span is not None and span[0] > got[0]["end_time"] and span[1] < got[-1]["start_time"]
+
+
+def test_detect_10bit_uses_8bit_gray_units(tmp_path):
+    w, h, fps, n = 96, 64, 30, 120
+    runs = [(5, 14), (100, 110)]
+    path, frames = _clip_with_bookends(tmp_path, w, h, n, fps, runs, bpc=10)
+    rd = yuvio.open_video(path)
+    got = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd))
+    _same(got, _reference_style_detect(frames, fps, bpc=10))
+    assert [(b["start_frame"], b["end_frame"]) for b in got] == runs
+
+
+def test_detect_needs_an_engine_or_stats_fn(tmp_path):
+    path, _ = _clip_with_bookends(tmp_path, 64, 48, 10, 30, [])
+    with pytest.raises(ValueError):
+        bookend.detect(yuvio.open_video(path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bpc,w,h", [(8, 640, 360), (10, 322, 182)])
+def test_detect_on_the_gpu_engine(tmp_path, bpc, w, h):
+    """detect() through pqa_luma_stats (host frames -> pinned staging -> luma_stats_kernel): the exact integer
+    reductions make every decision identical to the numpy-driven run and to the reference-style loop."""
+    from pqa2_amd.engine import FeatureEngine
+    fps, n, runs = 30, 150, [(3, 11), (128, 140)]
+    path, frames = _clip_with_bookends(tmp_path, w, h, n, fps, runs, bpc=bpc, partial=(12, 0.85))
+    rd = yuvio.open_video(path)
+    with FeatureEngine(w, h, bit_depth=bpc, max_batch=4) as eng:
+        # the entry point itself: sampled, non-contiguous host frames, more than one staging chunk
+        idx = list(range(0, n, 7))
+        st = eng.luma_stats([rd.frame(i)[0] for i in idx], 200 << (bpc - 8))
+        assert np.array_equal(st, bookend.numpy_stats_fn(rd)(idx, 200 << (bpc - 8)))
+        got = bookend.detect(rd, eng)
+    cpu = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd))
+    assert got == cpu                       # same integers in, same floats out
+    _same(got, _reference_style_detect(frames, fps, bpc=bpc))
+    assert [(b["start_frame"], b["end_frame"]) for b in got][0][0] == runs[0][0]
