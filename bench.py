@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the extra 1080p measurement the default 2160p run appends as `other_configs`")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end leg (Y4M files -> VMAFAnalyzer.analyze_videos -> JSON + stats files)")
+    ap.add_argument("--cpu-all-cores", action="store_true", help=argparse.SUPPRESS)  # kept for scripts; the all-core leg is on by default
     ap.add_argument("--fixed-point", type=int, default=0,
                     help="PQA_FIXED_* mask (1 VIF, 2 motion): measure libvmaf's fixed-point arithmetic instead of the "
                          "default f32 path")
@@ -120,13 +123,31 @@ def main():
     def step():
         eng.reset()
         eng.submit_resident(a, F, ref_ptrs, dis_ptrs, row_pitch, frame_pitch, halo_ptr, row_pitch[0])
-        rec = eng.collect(a, F)
-        full = shard.gather_records(rec, total, world, rank, gather_dev)
-        # every rank now holds all records (motion2 needs the neighbour's motion); it runs the SVM for its own
-        # frames only and a second 8-byte-per-frame gather collects the scores: no serial host stage at N = 8
-        metrics = M.metrics_from_records(full, w, h, prefix)
-        mine = {k: v[a:a + F] for k, v in metrics.items()}
-        vmaf = shard.gather_vector(M.score_frames(model, mine)["vmaf"], total, world, rank, gather_dev)
+        # records come back batch by batch: pqa_collect waits for ITS batch only (per-batch completion events), so the
+        # host's share (feature epilogues + SVM) of batch k runs while the GPU works on batches k+1..  motion2 of a
+        # frame needs its successor's motion: the last frame of what has arrived is scored with the next batch.
+        rec = np.empty((F, N.RECORD_DOUBLES))
+        vm_local = np.empty(F)
+        scored = 0
+        for b0 in range(0, F, args.batch):
+            n = min(args.batch, F - b0)
+            rec[b0:b0 + n] = eng.collect(a + b0, n)
+            if world == 1:
+                e = b0 + n
+                upto = e if e == F else e - 1
+                if upto > scored:
+                    m = M.metrics_from_records(rec[scored:e], w, h, prefix)
+                    vm_local[scored:upto] = M.score_frames(model, {k: v[:upto - scored] for k, v in m.items()})["vmaf"]
+                    scored = upto
+        if world == 1:
+            full, vmaf = rec, vm_local
+        else:
+            full = shard.gather_records(rec, total, world, rank, gather_dev)
+            # every rank now holds all records (motion2 needs the neighbour's motion); it runs the SVM for its own
+            # frames only and a second 8-byte-per-frame gather collects the scores: no serial host stage at N = 8
+            metrics = M.metrics_from_records(full, w, h, prefix)
+            mine = {k: v[a:a + F] for k, v in metrics.items()}
+            vmaf = shard.gather_vector(M.score_frames(model, mine)["vmaf"], total, world, rank, gather_dev)
         if rank == 0:
             result["records"] = full
             result["vmaf"] = vmaf
@@ -180,15 +201,32 @@ def main():
             avg_ms = k["ms"] / k["launches"]
             frames_per_launch = k["frames"] / k["launches"]
             achieved = b_alg * frames_per_launch / (avg_ms * 1e-3) / 1e9
-            per_frame = None if args.fixed_point & 1 else _traffic_from_profiles(args.workload)
+            cnt = {} if args.fixed_point & 1 else _kernel_counters(args.workload, "vif_stat_s0")
+            per_frame = cnt.get("hbm_bytes_per_frame")
             traffic = int(per_frame * frames_per_launch) if per_frame else None
             kname = ("vif_fixed_kernel" if args.fixed_point & 1 else "vif_stat_kernel") + f"<{'u8' if bpc == 8 else 'u16'},17,240,9>"
             out["roofline"] = {"bound": "hbm", "kernel": kname + " (VIF scale 0 + fused decimation to scale 1)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5),
                                "traffic": traffic,
+                               "traffic_source": cnt.get("traffic_source", "no PMC pass committed for this workload / kernel source"),
                                "alg_bytes_per_launch": int(b_alg * frames_per_launch),
-                               "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"]}
+                               "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"],
+                               # SURVEY 8(d)'s primary formula for the WHOLE path: frames/s x B_alg / HBM peak
+                               "pipeline_frac": round(fps / world * b_alg / (HBM_PEAK_GBS * 1e9), 5),
+                               # what actually limits the kernel: FP32 issue, not bytes
+                               "measured_limiter": "valu-issue (FP32 FMA rate), not HBM: see `valu`"}
+            if cnt.get("valu_insts_per_wave"):
+                # issue floor = VALU instructions per wave x waves / (1024 SIMDs x one wave64 instruction per 4 clocks)
+                clk = cnt.get("shader_clock_ghz", 2.0)
+                floor_us = cnt["valu_insts_per_wave"] * cnt["waves_per_frame"] * 4.0 / (1024 * clk * 1e3)
+                meas_us = 1e3 * avg_ms / frames_per_launch
+                out["roofline"]["valu"] = {
+                    "valu_insts_per_wave": cnt["valu_insts_per_wave"], "waves_per_frame": cnt["waves_per_frame"],
+                    "shader_clock_ghz": clk, "issue_floor_us_per_frame": round(floor_us, 2),
+                    "measured_us_per_frame": round(meas_us, 2), "frac": round(floor_us / meas_us, 4),
+                    "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk (v_pk_fma_f32 = 2 FMA per lane: 157 TFLOP/s)",
+                    "source": cnt.get("valu_source")}
             out["kernel_ms_per_frame"] = {name: round(v["ms"] / max(1, v["frames"]), 5)
                                           for name, v in breakdown.items() if v["launches"]}
             out["kernel_ms_note"] = "from one extra untimed pass with every kernel event-timed (ms per frame)"
@@ -200,6 +238,9 @@ def main():
                                                 result["records"], model, prefix)
         if world == 1 and args.workload == "2160p" and not args.fixed_point and not args.no_other_configs:
             out["other_configs"] = _other_configs(args)
+        if world == 1 and args.workload == "2160p" and not args.fixed_point and not args.no_e2e:
+            out["e2e"] = _e2e_leg()
+        out["libvmaf_side_by_side"] = "not available: no ffmpeg / libvmaf on this box (cpu_baseline.kind = port)"
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
@@ -207,30 +248,86 @@ def main():
 
 
 def _other_configs(args):
-    """BASELINE.json names 1080p (configs[1]) next to the 4K headline: measure it too, in a child process with the same
-    step definition (its own context and clip), and carry its line's essentials along.  Never part of `value`."""
+    """BASELINE.json names 1080p (configs[1]) and 2160p 10-bit neg + PSNR + SSIM (configs[4]) next to the 4K headline:
+    measure them too, each in a child process with the same step definition (its own context and clip), and carry the
+    essentials of their lines along.  Never part of `value`."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "1080p", "--steps", str(max(3, args.steps)),
-           "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-other-configs"]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-        d = json.loads(r.stdout.strip().splitlines()[-1])
-        return {"1080p": {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                          "workload": d["config"]["workload"], "roofline_frac": d.get("roofline", {}).get("frac")}}
-    except Exception as e:  # the headline must not depend on this
-        return {"1080p": {"error": str(e)[:200]}}
+    res = {}
+    for wl in ("1080p", "2160p10"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(max(3, args.steps)),
+               "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-other-configs", "--no-e2e"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            res[wl] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                       "workload": d["config"]["workload"], "roofline_frac": d.get("roofline", {}).get("frac"),
+                       "pipeline_frac": d.get("roofline", {}).get("pipeline_frac")}
+        except Exception as e:  # the headline must not depend on this
+            res[wl] = {"error": str(e)[:200]}
+    return res
 
 
-def _traffic_from_profiles(workload: str):
-    """HBM bytes per FRAME of the dominant kernel from the committed rocprofv3 --pmc passes, if any
-    (bench.py cannot collect PMC counters itself; tools/summarize_rocprof.py writes this file)."""
-    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def _e2e_leg():
+    """SURVEY 8(d) end-to-end leg: two 4:2:0 Y4M files on disk -> VMAFAnalyzer.analyze_videos() (host planes -> pinned
+    staging -> H2D overlapped with the kernels -> SVM -> libvmaf-format JSON + psnr/ssim stats files), wall clock, in a
+    child process per size (tools/e2e_file_bench.py).  PCIe- and memcpy-bound; never part of `value`."""
+    import shutil
+    import subprocess
+    import tempfile
+    out = {}
+    for size, frames in (("1920x1080", 150), ("3840x2160", 48)):
+        d = tempfile.mkdtemp(prefix="pqa_e2e_")
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_file_bench.py"), "--size", size,
+                                "--frames", str(frames), "--dir", d], capture_output=True, text=True, timeout=300)
+            lines = [json.loads(x) for x in r.stdout.strip().splitlines() if x.startswith("{")]
+            best = max(lines, key=lambda x: x["fps_end_to_end"])
+            out[size] = {"fps_end_to_end": best["fps_end_to_end"], "frames": frames, "seconds": best["seconds"],
+                         "what": "2 Y4M files (page cache) -> analyze_videos -> JSON + psnr.txt + ssim.txt, all planes, "
+                                 "vmaf_v0.6.1; context creation and file writing included"}
+        except Exception as e:
+            out[size] = {"error": (str(e) or "failed")[:200]}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the sources of the dominant kernel: counters measured for another version of it are stale."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("vif.hip", "pqa_device.h", "kernels.h"):
+        with open(os.path.join(ROOT, "pqa2_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def _kernel_counters(workload: str, kernel: str) -> dict:
+    """Per-frame PMC figures of a kernel from the committed rocprofv3 passes (bench.py cannot collect PMC counters
+    itself; tools/profile_round.sh + tools/summarize_rocprof.py write profiles/kernel_counters.json).  Figures measured
+    on a DIFFERENT version of the kernel source are dropped, and the line says so."""
+    p = os.path.join(ROOT, "profiles", "kernel_counters.json")
     try:
         with open(p) as f:
-            d = json.load(f)
-        return d.get(workload, {}).get("vif_stat_s0_bytes_per_frame")
+            d = json.load(f).get(workload, {}).get(kernel, {})
     except Exception:
-        return None
+        return {}
+    if not d:
+        return {}
+    if d.get("src_hash") != kernel_source_hash():
+        return {"traffic_source": f"{d.get('traffic_source', p)} is for kernel source {d.get('src_hash')}, the kernel has "
+                                  f"changed since (now {kernel_source_hash()}): dropped as stale"}
+    return d
+
+
+def _cgroup_cpu_max():
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(p) as f:
+                return f.read().strip()
+        except Exception:
+            pass
+    return None
 
 
 def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads, gpu_records, model, prefix):
@@ -262,7 +359,33 @@ def _cpu_baseline(ref_t, dis_t, halo, bpc, w, h, n_sample, threads, gpu_records,
     t0 = time.perf_counter()
     into.clip_features_mt(refs[:n_fx], diss[:n_fx], bpc, threads, model.vif_enhn_gain_limit, model.adm_enhn_gain_limit)
     dt_fx = time.perf_counter() - t0
+    # the same restatement on every core this process may use ("all cores, labelled")
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or threads)
+    quota = _cgroup_cpu_max()
+    try:   # a container's CPU quota caps what "all cores" means: 256 visible cores under a 16-CPU quota are 16 cores
+        q, per = quota.split()[:2]
+        if q != "max":
+            avail = max(1, min(avail, int(int(q) / int(per))))
+    except Exception:
+        pass
+    all_core = None
+    if avail > threads:
+        n_all = min(ref_t[0].shape[0] - halo, avail)
+        more_r = refs + [ref_t[0][halo + i].cpu().numpy() for i in range(n_sample, n_all)]
+        more_d = diss + [dis_t[0][halo + i].cpu().numpy() for i in range(n_sample, n_all)]
+        if bpc > 8:
+            more_r = [r.view(np.uint16) for r in more_r]
+            more_d = [d.view(np.uint16) for d in more_d]
+        t0 = time.perf_counter()
+        orc.clip_features_mt(more_r[:n_all], more_d[:n_all], bpc, avail, vif_gain_limit=model.vif_enhn_gain_limit,
+                             adm_gain_limit=model.adm_enhn_gain_limit, vif_border101=bool(model.vif_border))
+        dt_all = time.perf_counter() - t0
+        all_core = {"value": round(n_all / dt_all, 4), "cores": avail, "cgroup_cpu_max": _cgroup_cpu_max(),
+                    "sample": f"first {n_all} frames, one frame per thread on all {avail} schedulable cores, {dt_all:.1f} s"}
+        del more_r, more_d
     return {"value": round(n_sample / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "all_cores": all_core if all_core else f"{avail} usable cores (affinity {len(os.sched_getaffinity(0))}, cgroup cpu.max "
+                                                   f"'{quota}'): the {threads}-thread figure IS the all-core figure of this box share",
             "fixed_point_port_value": round(n_fx / dt_fx, 4),
             "fixed_point_port_sample": f"first {n_fx} frames, oracle/vmaf_int_oracle.c, {dt_fx:.1f} s on {threads} threads",
             "sample": f"first {n_sample} frames of the same clip, oracle/vmaf_oracle.c f32 (VIF+ADM+motion), "

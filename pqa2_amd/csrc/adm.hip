@@ -86,12 +86,27 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
     if (col < VC) {
       const unsigned gx = (unsigned)mirror1(2 * cx0 - 3 + col, a.w);
       f2 x[NIN];
+      // Row offsets are wave-uniform (SGPRs).  A strip whose NIN input rows all lie inside the image -- every strip
+      // but the first and last tile rows' -- needs no mirroring: offset = (y0 + j) * pitch with j a literal, 2 scalar
+      // ops per row instead of 8 (the mirror's abs / compare / select / clamp plus two multiplies).  The branch is
+      // wave-uniform; both arms feed the same DWT code below.
+      const int y0 = 2 * cy0 - 3 + 2 * SROWS * strip;
+      if (y0 >= 0 && y0 + NIN <= a.h) {
+        const unsigned base_r = (unsigned)y0 * pitch_r, base_d = (unsigned)y0 * pitch_d;
 #pragma unroll
-      for (int j = 0; j < NIN; ++j) {
-        const unsigned gy = (unsigned)mirror1(2 * cy0 - 3 + 2 * SROWS * strip + j, a.h);
-        const T r = buf_load<T>(rsrc_r, gx, gy * pitch_r);  // row offset rides in an SGPR
-        const T d = buf_load<T>(rsrc_d, gx, gy * pitch_d);
-        x[j] = PixIO<T>::pair(r, d, a.inv_scale);
+        for (int j = 0; j < NIN; ++j) {
+          const T r = buf_load<T>(rsrc_r, gx, base_r + (unsigned)j * pitch_r);  // row offset rides in an SGPR
+          const T d = buf_load<T>(rsrc_d, gx, base_d + (unsigned)j * pitch_d);
+          x[j] = PixIO<T>::pair(r, d, a.inv_scale);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+          const unsigned gy = (unsigned)mirror1(y0 + j, a.h);
+          const T r = buf_load<T>(rsrc_r, gx, gy * pitch_r);
+          const T d = buf_load<T>(rsrc_d, gx, gy * pitch_d);
+          x[j] = PixIO<T>::pair(r, d, a.inv_scale);
+        }
       }
 #pragma unroll
       for (int p = 0; p < SROWS / 2; ++p) {
@@ -127,7 +142,10 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
   const int lcx = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // row pairs are per wave: row tests stay scalar
   const bool have = lcx < GW;
-  const int lcxs = have ? lcx : 0;
+  // lanes 62, 63 have no column.  They used to read column 0: in their ds_read_b128 service group {36-43, 48-51,
+  // 60-63} that address shares banks with lanes 48-51 -> a 2-way conflict on every V read (12.7 % of LDS cycles,
+  // profiles/r01f_2160p_sq_counters.txt).  Reading lane 61's address instead is a broadcast: free.
+  const int lcxs = have ? lcx : GW - 1;
   const int cx = cx0 - 1 + lcxs;
   const bool col_valid = have && cx >= 0 && cx < a.ow;
   const bool col_inner = col_valid && lcxs >= 1 && lcxs <= TW;
@@ -228,8 +246,9 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
     // band-level mirror of the 3x3 neighbourhood (only bites when the window touches the border)
     // (clamped into the written part of G: the halo columns themselves look one column further out, carry
     // weight 0, and must not pull uninitialised LDS -- possibly NaN bits -- into a 0 * x product)
-    const int lx0 = have ? min(max(mirror1(cx - 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
-    const int lx2 = have ? min(max(mirror1(cx + 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
+    // (lanes 62, 63 carry lane 61's cx: the same addresses as lane 61 -> broadcasts, no bank conflict)
+    const int lx0 = min(max(mirror1(cx - 1, a.ow) - (cx0 - 1), 0), GW - 1);
+    const int lx2 = min(max(mirror1(cx + 1, a.ow) - (cx0 - 1), 0), GW - 1);
 #pragma unroll
     for (int k = 0; k < NROUND; ++k) {
       const int rp = wave + 4 * k;

@@ -13,9 +13,11 @@ ap.add_argument("--size", default="3840x2160")
 ap.add_argument("--frames", type=int, default=96)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--features", type=int, default=7, help="PQA_FEAT_* mask: 1 VIF, 2 ADM, 4 motion (isolate one chain)")
+ap.add_argument("--bits", type=int, default=8)
 a = ap.parse_args()
 w, h = map(int, a.size.split("x"))
-clip = synth_torch.make_clip_cuda(w, h, a.frames, 8)
+clip = synth_torch.make_clip_cuda(w, h, a.frames, a.bits)
 R, D = clip["ref"][0], clip["dis"][0]
 torch.cuda.synchronize()
 
@@ -27,15 +29,16 @@ def bind(path):
     lib.pqa_destroy.argtypes = [vp]; lib.pqa_destroy.restype = None
     lib.pqa_submit_device.argtypes = [vp, i64, i32, C.POINTER(N.PqaDeviceClip), C.POINTER(N.PqaDeviceClip), vp, i64]
     lib.pqa_sync.argtypes = [vp]; lib.pqa_reset.argtypes = [vp]
-    cfg = N.PqaConfig(); lib.pqa_config_init(C.byref(cfg), w, h); cfg.max_batch = a.batch
+    cfg = N.PqaConfig(); lib.pqa_config_init(C.byref(cfg), w, h); cfg.max_batch = a.batch; cfg.features = a.features; cfg.bit_depth = a.bits
     ctx = vp(); assert lib.pqa_create(C.byref(cfg), C.byref(ctx)) == 0
     return lib, ctx
 
 ctxs = [bind(p) for p in a.libs]
 r, d = N.PqaDeviceClip(), N.PqaDeviceClip()
 r.plane[0], d.plane[0] = R.data_ptr(), D.data_ptr()
-r.row_pitch[0] = d.row_pitch[0] = w
-r.frame_pitch[0] = d.frame_pitch[0] = w * h
+es = 1 if a.bits <= 8 else 2
+r.row_pitch[0] = d.row_pitch[0] = w * es
+r.frame_pitch[0] = d.frame_pitch[0] = w * h * es
 def run(lib, ctx):
     lib.pqa_reset(ctx)
     t = time.perf_counter()

@@ -35,8 +35,11 @@ def load(d):
     return acc, n, dur
 
 
-a, na, dur = load(sys.argv[1])
-b, nb, _ = load(sys.argv[2])
+args = [x for x in sys.argv[1:] if not x.startswith("--json")]
+json_out = next((x.split("=", 1)[1] for x in sys.argv[1:] if x.startswith("--json=")), None)
+a, na, dur = load(args[0])
+b, nb, _ = load(args[1])
+summary = {}
 print("# rocprofv3 --pmc SQ_* (two passes); cycles = counter x 4 (SQ_*CYCLES count quad-cycles);")
 print("# 'valu_act % of wave life' x waves per SIMD = VALU busy share")
 for k in sorted(a, key=lambda k: -dur[k]):
@@ -46,6 +49,15 @@ for k in sorted(a, key=lambda k: -dur[k]):
     wb = b[k]["SQ_WAVES"] if b[k].get("SQ_WAVES") else w * nb[k] / max(na[k], 1)
     wait = 4 * b[k]["SQ_WAIT_ANY"] / max(wb, 1.0)
     conf = b[k]["SQ_LDS_BANK_CONFLICT"] / max(b[k]["SQ_LDS_IDX_ACTIVE"], 1.0)
+    # effective shader clock: GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+    gui = b[k].get("GRBM_GUI_ACTIVE", 0.0)
+    clk = gui / 8.0 / max(nb[k], 1) / max(dur[k] / na[k] * 1e-6, 1e-12) / 1e9 if gui else 0.0
+    summary[k] = {"valu_per_wave": a[k]["SQ_INSTS_VALU"] / w, "salu_per_wave": a[k]["SQ_INSTS_SALU"] / w,
+                  "waves_per_launch": w / max(na[k], 1), "us_per_launch": dur[k] / na[k],
+                  "lds_conflict_frac": conf, "valu_active_frac_of_wave_life": act / max(life, 1), "clock_ghz": clk}
     print(f"{k:46s} us/launch={dur[k] / na[k]:8.1f} VALU/w {a[k]['SQ_INSTS_VALU'] / w:6.0f} SALU {a[k]['SQ_INSTS_SALU'] / w:5.0f} "
           f"LDS {a[k]['SQ_INSTS_LDS'] / w:5.0f} life {life:7.0f} valu_act {act:6.0f} ({100 * act / max(life, 1):3.0f}% of wave life) "
           f"wait_any {100 * wait / max(life, 1):3.0f}% lds_conflict/active {100 * conf:4.1f}%")
+if json_out:
+    import json
+    json.dump(summary, open(json_out, "w"), indent=1)

@@ -12,8 +12,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--stats"); ap.add_argument("--fetch"); ap.add_argument("--write")
 ap.add_argument("--tag", required=True); ap.add_argument("--frames-per-launch", type=float, default=8)
 ap.add_argument("--workload", default="2160p")
+ap.add_argument("--sq-json", help="JSON written by tools/sq_counters.py --json: VALU instructions per wave etc.")
+ap.add_argument("--out", help="directory to write into (default: <repo>/profiles); on the GPU box use gpurun_out/...")
 a = ap.parse_args()
-root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = a.out or os.path.join(REPO, "profiles")
 os.makedirs(root, exist_ok=True)
 
 def short(name):
@@ -61,11 +64,25 @@ if pmc:
                    "kernels read 1-4 B/lane row segments, so treat the absolute as +-2x and the ratios as exact.",
            "kernels": pmc}
     json.dump(out, open(os.path.join(root, f"{a.tag}_pmc.json"), "w"), indent=1)
-    k0 = next((k for k in pmc if k.startswith("vif_stat_kernel<unsigned char, 17")), None)
-    tj = os.path.join(root, "hbm_traffic.json")
+    # machine-readable figures of the dominant kernel for bench.py (`roofline.traffic`, `roofline.valu`), stamped with a
+    # hash of the kernel's source so that bench.py drops them once the kernel changes
+    import sys
+    sys.path.insert(0, REPO)
+    from bench import kernel_source_hash
+    pref = {"2160p": "unsigned char, 17", "1080p": "unsigned char, 17", "2160p10": "unsigned short, 17"}[a.workload]
+    k0 = next((k for k in pmc if k.startswith("vif_stat_kernel<" + pref) or k.startswith("vif_s0_mfma_kernel<" + pref)), None)
+    tj = os.path.join(root, "kernel_counters.json")
     cur = json.load(open(tj)) if os.path.exists(tj) else {}
     if k0:
-        cur[a.workload] = {"vif_stat_s0_bytes_per_frame": int(pmc[k0]["hbm_bytes_per_frame_corrected"]),
-                           "measured_at_frames_per_launch": a.frames_per_launch, "source": f"profiles/{a.tag}_pmc.json"}
+        e = {"kernel": k0, "hbm_bytes_per_frame": int(pmc[k0]["hbm_bytes_per_frame_corrected"]),
+             "measured_at_frames_per_launch": a.frames_per_launch, "src_hash": kernel_source_hash(),
+             "traffic_source": f"profiles/{a.tag}_pmc.json (committed rocprofv3 --pmc passes, not this run)"}
+        if a.sq_json:
+            sq = json.load(open(a.sq_json)).get(k0, {})
+            if sq:
+                e.update({"valu_insts_per_wave": round(sq["valu_per_wave"], 1), "waves_per_frame": int(round(sq["waves_per_launch"] / a.frames_per_launch)),
+                          "shader_clock_ghz": round(sq.get("clock_ghz", 2.0), 3),
+                          "valu_source": f"profiles/{a.tag}_sq_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, committed)"})
+        cur.setdefault(a.workload, {})["vif_stat_s0"] = e
         json.dump(cur, open(tj, "w"), indent=1)
 print("ok")
