@@ -16,6 +16,10 @@
 //   3. statistic on the pair, DPP wave sum, one (num, den) double partial per tile; a fixed-order second
 //      stage (finalize.hip) makes 1..8-GPU results bit-identical.
 // HBM traffic: the two input planes once (halo re-reads hit L2) + the half-resolution planes written once.
+#include <cstring>
+#include <mutex>
+#include <vector>
+
 #include "kernels.h"
 #include "pqa_device.h"
 
@@ -73,17 +77,164 @@ struct VifStatArgs {
   float* dst_ref;
   float* dst_dis;
   int64_t dst_row_pitch_r, dst_frame_pitch_r, dst_row_pitch_d, dst_frame_pitch_d;
+  // Scale 0 of 8-bit clips splits the tile grid: the interior rectangle [tx_lo, tx_hi) x [ty_lo, ty_hi) (ty in pairs)
+  // goes to vif_s0_mfma_kernel, this kernel takes the border tiles only (edge_only; grid = number of border tiles).
+  int edge_only, tx_lo, tx_hi, ty_lo, ty_hi;
+  const uint4* atab;   // MFMA kernel: per-lane tap-matrix fragments (kAtabFrags x 64 lanes x 8 f16)
   TapPairs taps;
 };
 
+// Border tile number e (0 .. n_border) -> tile id in the full grid: the rows above and below the interior rectangle
+// in full, then the left / right flanks of the rows beside it.
+__device__ __forceinline__ int border_tile(int e, const VifStatArgs& a) {
+  const int W = a.tiles_x, top = a.ty_lo * W;
+  if (e < top) return e;
+  e -= top;
+  const int tiles_y = a.n_tiles / W, bottom = (tiles_y - a.ty_hi) * W;
+  if (e < bottom) return a.ty_hi * W + e;
+  e -= bottom;
+  const int side = W - (a.tx_hi - a.tx_lo);
+  const int r = e / side, i = e - r * side;
+  return (a.ty_lo + r) * W + (i < a.tx_lo ? i : a.tx_hi + (i - a.tx_lo));
+}
+
 constexpr int kP2 = 258;  // LDS row pitch in float2: == 2 (mod 32) -> conflict-free ds_read_b128 (see below)
 
-// FP32 on gfx950 issues one wave64 VALU instruction per 4 cycles per SIMD; v_pk_fma_f32 does two FMAs
-// in that slot (measured: 74 TFLOP/s with v_fma_f32, 132-137 with v_pk_fma_f32, tools/ubench/fma_rate.hip).
-// Everything hot is therefore arranged as float2 = {row 2p, row 2p+1} of one column:
+// FP32 FMA throughput on gfx950 is 64 FLOP/clk/SIMD however it is issued (v_pk_fma_f32 every 4 clocks, plain
+// v_fma_f32 every 2 with >= 2 waves per SIMD, f32 MFMA: tools/ubench/pk_vs_plain.hip, mfma_coissue.hip); the packed
+// form halves the instruction count.  Everything hot is arranged as float2 = {row 2p, row 2p+1} of one column:
 //   vertical pass:   acc{2p,2p+1} += {c[k], c[k-1]} * {x, x}     (tap PAIR from SGPRs, input broadcast)
 //   horizontal pass: out{2p,2p+1}[o] += c[k] * in{2p,2p+1}[o+k]  (tap broadcast, input pair from LDS)
-template <typename T, int N, int TW, int ND>
+
+// Phases 1b (fused decimation), 2 (horizontal pass) and 3 (statistic + tile partial) of one TW x 8 tile whose
+// vertical-pass results are in LDS: sv[signal][row pair][column] = {row 2p, row 2p+1}, sd[even row][column] =
+// {ref, dis}.  Shared by the VALU kernel (vif_stat_kernel) and the matrix-core kernel (vif_s0_mfma_kernel).
+template <int N, int TW, int ND>
+__device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* [5][TH/2][kP2] */,
+                                          const f2* sd /* [TH/2][kP2] */, double* red, int fr, int tile, int x0, int y0) {
+  constexpr int R = N / 2, TH = kVifTileH, NSEG = TW / 4, NRP = TH / 2;
+  constexpr int RD = ND / 2;
+  const int tid = threadIdx.x;
+  fr = __builtin_amdgcn_readfirstlane(fr); tile = __builtin_amdgcn_readfirstlane(tile);   // workgroup-uniform: keep
+  x0 = __builtin_amdgcn_readfirstlane(x0); y0 = __builtin_amdgcn_readfirstlane(y0);       // the address math scalar
+  // ---- 1b. fused decimation: horizontal pass at even columns, written straight to the next scale --
+  if (ND) {
+    const int ox0 = x0 >> 1, oy0 = y0 >> 1, ow = a.w >> 1, oh = a.h >> 1;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const int item = tid + round * kBlock;
+      const int oc = item & 127, orow = item >> 7;  // 128 slots per row, TW/2 of them used
+      const int gx = ox0 + oc, gy = oy0 + orow;
+      if (oc < TW / 2 && gx < ow && gy < oh) {
+        f2 acc = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < ND; ++k) acc = __builtin_elementwise_fma(a.taps.dt[k], sd[orow * kP2 + 2 * oc + (R - RD) + k], acc);
+        a.dst_ref[(int64_t)fr * a.dst_frame_pitch_r + (int64_t)gy * a.dst_row_pitch_r + gx] = acc.x;
+        a.dst_dis[(int64_t)fr * a.dst_frame_pitch_d + (int64_t)gy * a.dst_row_pitch_d + gx] = acc.y;
+      }
+    }
+  }
+
+  // ---- 2. horizontal pass + 3. statistic --------------------------------------------------------
+  // lane l: row pair rp = l & 3, segment (4 columns) seg = 2*(s&3) + (wave&1) + 8*(s>>2) + 32*(wave>>1)
+  // with s = l >> 2.  The row-pair pitch is 129 16-byte chunks (== 1 mod 16) and 2*seg == 4*s + const
+  // (mod 16), so a lane's chunk index is l + const (mod 16): consecutive lanes hit consecutive chunks,
+  // which is conflict-free for every ds_read_b128 lane group.
+  const int wave = tid >> 6, lane = tid & 63;
+  const int rp = lane & 3, sl = lane >> 2;
+  const int seg = 2 * (sl & 3) + (wave & 1) + 8 * (sl >> 2) + 32 * (wave >> 1);
+  float num = 0.0f, den = 0.0f;
+  if (seg < NSEG) {
+    constexpr int NCOL = 4 + N - 1, NREAD = (NCOL + 1) / 2;
+    f2 out[5][4];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      f2 in[2 * NREAD];
+      const f4* p = reinterpret_cast<const f4*>(&sv[(s * NRP + rp) * kP2 + seg * 4]);
+#pragma unroll
+      for (int q = 0; q < NREAD; ++q) {
+        const f4 v = p[q];
+        in[2 * q] = f2{v.x, v.y};
+        in[2 * q + 1] = f2{v.z, v.w};
+      }
+      // tap-major order: the four outputs are independent chains, so consecutive v_pk_fma_f32 never
+      // depend on each other (a dependent pair costs an s_nop); each output still sums taps 0..N-1 in order
+#pragma unroll
+      for (int o = 0; o < 4; ++o) out[s][o] = f2{0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) out[s][o] = __builtin_elementwise_fma(a.taps.ht[k], in[o + k], out[s][o]);
+      __builtin_amdgcn_sched_barrier(0);  // one signal's 10 ds_read_b128 in flight at a time, not all 50
+    }
+    const float sigma_nsq = 2.0f, eps = 1.0e-10f, sigma_max_inv = 4.0f / (255.0f * 255.0f);
+    // validity as 0/1 weights folded into the accumulation (an fma instead of an add): no branches, and
+    // out-of-image positions of edge tiles still hold finite values (mirrored real pixels)
+    const int gyA = y0 + 2 * rp;
+    const bool vrow[2] = {gyA < a.h, gyA + 1 < a.h};
+    f2 num2 = f2{0.0f, 0.0f}, den2 = f2{0.0f, 0.0f};
+    // the log terms of the sigma1_sq >= sigma_nsq branch are summed as the log of a product: per row of
+    // the pair the four columns' arguments (each in [2, 2^15]) are multiplied first, so the thread takes
+    // 6 v_log_f32 instead of 16 and needs no reciprocal for num's ratio (log a/b = log a - log b)
+    f2 pn = f2{1.0f, 1.0f}, qn = f2{1.0f, 1.0f}, pd = f2{1.0f, 1.0f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const bool vcol = (x0 + seg * 4 + o) < a.w;
+      // the two rows of the pair go through the statistic together: every add / mul / fma is packed,
+      // only max / min / select / rcp / log are per element
+      const f2 mu1 = out[0][o], mu2 = out[1][o];
+      f2 s1 = out[2][o] - mu1 * mu1, s2 = out[3][o] - mu2 * mu2;
+      const f2 s12 = out[4][o] - mu1 * mu2;
+      s1 = f2{fmaxf(s1.x, 0.0f), fmaxf(s1.y, 0.0f)};
+      s2 = f2{fmaxf(s2.x, 0.0f), fmaxf(s2.y, 0.0f)};
+      // g = sigma12 / (sigma1_sq + eps): v_rcp_f32 plus one Newton correction -- exact 1.0 when the two
+      // are equal (identical frames), 2 FMAs instead of a full IEEE division
+      const f2 gden = s1 + f2{eps, eps};
+      const f2 grcp = f2{fast_rcp(gden.x), fast_rcp(gden.y)};
+      f2 g = s12 * grcp;
+      g = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, gden, s12), grcp, g);
+      f2 sv = s2 - g * s12;
+      // vif_statistic_s also has `if (sigma1_sq < eps) {g = 0; sv_sq = sigma2_sq; sigma1_sq = 0}` and
+      // `if (g < 0) {sv_sq = sigma2_sq; g = 0}`.  Both are dead for the result: the first implies
+      // sigma1_sq < sigma_nsq and the second implies sigma12 < 0, and each of those overrides num/den below.
+      if (s2.x < eps) { g.x = 0.0f; sv.x = 0.0f; }
+      if (s2.y < eps) { g.y = 0.0f; sv.y = 0.0f; }
+      sv = f2{fmaxf(sv.x, eps), fmaxf(sv.y, eps)};
+      // clamp g to [0, gain_limit] with one v_med3_f32: the upper bound is vif_enhn_gain_limit, the lower
+      // bound makes g*g = 0 when sigma12 < 0, i.e. num_val = log2(1) = 0 -- libvmaf's `if (sigma12 < 0) num_val = 0`
+      g = f2{__builtin_amdgcn_fmed3f(g.x, 0.0f, a.gain_limit), __builtin_amdgcn_fmed3f(g.y, 0.0f, a.gain_limit)};
+      const f2 svn = sv + f2{sigma_nsq, sigma_nsq};
+      // num_val = log2(1 + g^2 sigma1_sq / (sv_sq + sigma_nsq)) = log2(narg) - log2(svn)
+      const f2 narg = __builtin_elementwise_fma(g * g, s1, svn);
+      const f2 darg = __builtin_elementwise_fma(s1, f2{1.0f / sigma_nsq, 1.0f / sigma_nsq}, f2{1.0f, 1.0f});
+      const f2 low = __builtin_elementwise_fma(s2, f2{-sigma_max_inv, -sigma_max_inv}, f2{1.0f, 1.0f});
+      // validity and the branch choice as selects: out-of-image positions of edge tiles hold finite values
+      // (mirrored real pixels), they contribute a factor 1 and a weight 0
+      const bool vx = vcol && vrow[0], vy = vcol && vrow[1];
+      const bool hx = vx && !(s1.x < sigma_nsq), hy = vy && !(s1.y < sigma_nsq);
+      const bool lx = vx && (s1.x < sigma_nsq), ly = vy && (s1.y < sigma_nsq);
+      pn *= f2{hx ? narg.x : 1.0f, hy ? narg.y : 1.0f};
+      qn *= f2{hx ? svn.x : 1.0f, hy ? svn.y : 1.0f};
+      pd *= f2{hx ? darg.x : 1.0f, hy ? darg.y : 1.0f};
+      const f2 wl = f2{lx ? 1.0f : 0.0f, ly ? 1.0f : 0.0f};
+      num2 = __builtin_elementwise_fma(wl, low, num2);
+      den2 += wl;
+      __builtin_amdgcn_sched_barrier(0);  // two pixels' worth of temporaries live at a time
+    }
+    num = (num2.x + num2.y) + ((fast_log2(pn.x) - fast_log2(qn.x)) + (fast_log2(pn.y) - fast_log2(qn.y)));
+    den = (den2.x + den2.y) + (fast_log2(pd.x) + fast_log2(pd.y));
+  }
+  const float part[2] = {num, den};
+  double v[2];
+  block_sum_f32<2>(part, v, red);
+  if (tid == 0) {
+    double* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * 2;
+    out[0] = v[0];
+    out[1] = v[1];
+  }
+}
+
+template <typename T, int N, int TW, int ND, bool EDGE = false>
 __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a) {
   constexpr int R = N / 2, TH = kVifTileH, COLS = TW + N - 1, NSEG = TW / 4, S = 8, NIN = S + N - 1;
   constexpr int RD = ND / 2;  // ND = taps of the next scale's filter (0: last scale, no decimation)
@@ -94,7 +245,7 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
   __shared__ f2 sd[ND ? TH / 2 : 1][ND ? kP2 : 1];  // decimation: [even row][column] = {ref, dis}
   __shared__ double red[8];
 
-  const int tile = xcd_remap(blockIdx.x, a.n_tiles);
+  const int tile = EDGE ? border_tile(blockIdx.x, a) : xcd_remap(blockIdx.x, a.n_tiles);
   const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
   const int fr = blockIdx.y;
   const T* __restrict__ ref = (const T*)a.ref + (int64_t)fr * a.frame_pitch_r;
@@ -189,121 +340,242 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
   }
   __syncthreads();
 
-  // ---- 1b. fused decimation: horizontal pass at even columns, written straight to the next scale --
-  if (ND) {
-    const int ox0 = x0 >> 1, oy0 = y0 >> 1, ow = a.w >> 1, oh = a.h >> 1;
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-      const int item = tid + round * kBlock;
-      const int oc = item & 127, orow = item >> 7;  // 128 slots per row, TW/2 of them used
-      const int gx = ox0 + oc, gy = oy0 + orow;
-      if (oc < TW / 2 && gx < ow && gy < oh) {
-        f2 acc = f2{0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < ND; ++k) acc = __builtin_elementwise_fma(a.taps.dt[k], sd[orow][2 * oc + (R - RD) + k], acc);
-        a.dst_ref[(int64_t)fr * a.dst_frame_pitch_r + (int64_t)gy * a.dst_row_pitch_r + gx] = acc.x;
-        a.dst_dis[(int64_t)fr * a.dst_frame_pitch_d + (int64_t)gy * a.dst_row_pitch_d + gx] = acc.y;
-      }
-    }
-  }
+  vif_hstat<N, TW, ND>(a, &sv[0][0][0], &sd[0][0], red, fr, tile, x0, y0);
+}
 
-  // ---- 2. horizontal pass + 3. statistic --------------------------------------------------------
-  // lane l: row pair rp = l & 3, segment (4 columns) seg = 2*(s&3) + (wave&1) + 8*(s>>2) + 32*(wave>>1)
-  // with s = l >> 2.  The row-pair pitch is 129 16-byte chunks (== 1 mod 16) and 2*seg == 4*s + const
-  // (mod 16), so a lane's chunk index is l + const (mod 16): consecutive lanes hit consecutive chunks,
-  // which is conflict-free for every ds_read_b128 lane group.
-  const int wave = tid >> 6, lane = tid & 63;
-  const int rp = lane & 3, sl = lane >> 2;
-  const int seg = 2 * (sl & 3) + (wave & 1) + 8 * (sl >> 2) + 32 * (wave >> 1);
-  float num = 0.0f, den = 0.0f;
-  if (seg < NSEG) {
-    constexpr int NCOL = 4 + N - 1, NREAD = (NCOL + 1) / 2;
-    f2 out[5][4];
+
+// ================================================================================================================
+// Scale 0 of 8-bit clips on the matrix cores: the 17-tap VERTICAL pass as a banded-Toeplitz product with exact inputs.
+//
+// Why.  The VALU kernel above is bound by FP32 FMA throughput (64 FLOP/clk/SIMD, the same through v_pk_fma_f32, plain
+// v_fma_f32 and the f32 MFMA forms -- and packed FP32 shares its pipe with MFMA: tools/ubench/mfma_coissue.hip,
+// pk_vs_plain.hip); its vertical pass + sample conversion is 42 % of its issue cycles.  The f16 matrix pipe has 16x that
+// rate, and at scale 0 the filter INPUTS are small integers, so they can go through it without loss:
+//   * the five signals are split into base-256 digit planes of exact integers: r' = r-128, d' = d-128 (|.| <= 128);
+//     r'^2, d'^2 in [0, 16384] -> hi, lo with value = 256 hi + lo; r'd' in [-16256, 16384] -> hi = floor(./256) in
+//     [-64, 64], lo in [0, 255].  Every digit is exact in f16 (11-bit significand);
+//   * every f32 tap c is split into three f16 pieces of c * 2^19 (11 + 11 + 2 bits: exact, checked on the host; the
+//     2^19 keeps every piece a normal f16, the largest is 62 272 < 65 504).  Low digit planes use the first two pieces
+//     of c * 2^11 (22 bits: their weight is 2^-8 of the signal);
+//   * v_mfma_f32_16x16x32_f16: D[16 out rows][16 cols] += A[16][32 input rows] * B[32][16]; f16 x f16 products are
+//     exact in f32, the accumulator is f32.  A = the Toeplitz band of tap pieces (per-lane constants from a table),
+//     B = a digit plane.  16 output rows need exactly the 32 input rows one instruction holds.
+// The result is 2^11 (squares) / 2^19 (means) times the f32 convolution with an error below one f32 rounding of
+// libvmaf's own tap-by-tap sum; the factors are folded into the horizontal taps (exact powers of two).  The next
+// scale's input (9-tap filter, even rows) rides the same B operands with its own band matrix.
+//
+// Shape.  One workgroup = two vertically adjacent tiles of the VALU kernel's grid (TW x 16 outputs, 32 input rows).
+// Wave w owns input columns 64w..64w+63 in two passes of 32; lane l: n = l & 15 -> columns 2n, 2n+1 (one 16-bit load
+// per row: N-blocks b = 0, 1), g = l >> 4 -> input rows 8g..8g+7 (the K group of the B operand).  The output rows
+// are permuted in A so that accumulator registers {0,1} of lane group g are rows {2g, 2g+1} of the UPPER tile and
+// {2,3} the same rows of the LOWER tile: one ds_write_b128 per signal stores {row 2p, row 2p+1} x 2 columns in the
+// layout vif_hstat reads, conflict-free; the lower tile's half waits in registers while the upper tile runs its
+// horizontal pass + statistic, then takes its place in LDS (the LDS holds one 8-row tile: 3 workgroups per CU).
+// Only tiles whose 32 x 256 input window lies inside the image take this path (no mirroring: 86 % of the tiles at
+// 2160p, 72 % at 1080p); border tiles run vif_stat_kernel<.., EDGE>.  Both write the same per-tile partials.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef short s2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+constexpr int kAtabFrags = 8;  // 0-2: c*2^19 pieces (means, high digits)  3-4: c*2^11 pieces (low digits)  5-7: c'*2^18 (decimation)
+constexpr float kMfmaSqScale = 1.0f / 2048.0f;       // 2^-11: squares / cross term after the vertical pass
+constexpr float kMfmaMuScale = 1.0f / 256.0f;        // 2^-19 / 2^-11: the means carry 2^8 more
+constexpr float kMfmaDecScale = 1.0f / 262144.0f;    // 2^-18: decimation planes
+
+__device__ __forceinline__ h8 frag_from(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return __builtin_bit_cast(h8, u4v{a, b, c, d});
+}
+// two u8 (low bytes of the 16-bit halves of x) + 0x6400 -> two f16 (1024 + v): exact for v < 1024; then - bias
+__device__ __forceinline__ unsigned f16_pair_from_bytes(unsigned x, float bias) {
+  const h2 v = __builtin_bit_cast(h2, x | 0x64006400u) - h2{(_Float16)bias, (_Float16)bias};
+  return __builtin_bit_cast(unsigned, v);
+}
+// byte `which` (0 low, 1 high) of both 16-bit halves of x, each with 0x64 on top -> two f16 (1024 + byte), - bias
+__device__ __forceinline__ unsigned f16_pair_from_byte_of_halves(unsigned x, int which, float bias) {
+  const unsigned sel = which ? 0x04030401u : 0x04020400u;  // {0x64, byte, 0x64, byte}: source 0 = 0x64646464, source 1 = x
+  const unsigned p = __builtin_amdgcn_perm(0x64646464u, x, sel);
+  const h2 v = __builtin_bit_cast(h2, p) - h2{(_Float16)bias, (_Float16)bias};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArgs a) {
+  constexpr int N = 17, TW = 240, ND = 9, TH = kVifTileH;
+  __shared__ __attribute__((aligned(16))) f2 sv[5][TH / 2][kP2];
+  __shared__ __attribute__((aligned(16))) f2 sd[TH / 2][kP2];
+  __shared__ double red[8];
+
+  const int n_tx = a.tx_hi - a.tx_lo;
+  const int idx = xcd_remap(blockIdx.x, n_tx * ((a.ty_hi - a.ty_lo) >> 1));
+  const int tx = a.tx_lo + idx % n_tx, ty = a.ty_lo + 2 * (idx / n_tx);
+  const int fr = blockIdx.y;
+  const uint8_t* __restrict__ ref = (const uint8_t*)a.ref + (int64_t)fr * a.frame_pitch_r;
+  const uint8_t* __restrict__ dis = (const uint8_t*)a.dis + (int64_t)fr * a.frame_pitch_d;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+  const unsigned pitch_r = (unsigned)a.row_pitch_r, pitch_d = (unsigned)a.row_pitch_d;
+  const auto rsrc_r = make_rsrc(ref, (unsigned)a.h * pitch_r);
+  const auto rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d);
+
+  // tap-matrix fragments of this lane (A operand: row = lane & 15, K group = lane >> 4)
+  h8 A[kAtabFrags];
+#pragma unroll
+  for (int f = 0; f < kAtabFrags; ++f) A[f] = __builtin_bit_cast(h8, a.atab[f * 64 + lane]);
+
+  f4 park[2][5];   // lower tile's rows {2g, 2g+1} x columns {2n, 2n+1} per pass and signal
+  f4 park_d[2];    // lower tile's decimation row g: {ref, dis} x 2 columns
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int col0 = 64 * wave + 32 * pass + 2 * n;  // tile column (= LDS column) of N-block 0; N-block 1 is col0 + 1
+    const unsigned gx = (unsigned)(x0 - (N / 2) + col0);
+    const unsigned gy = (unsigned)(y0 - (N / 2) + 8 * g);
+    const unsigned off_r = gy * pitch_r + gx, off_d = gy * pitch_d + gx;
+    unsigned rr_[8], dr_[8];  // rows 8g+j: the two columns in the low 16 bits
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      rr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, off_r, (unsigned)j * pitch_r, 0);
+      dr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, off_d, (unsigned)j * pitch_d, 0);
+    }
+    f4 D[5][2], Dd[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int s = 0; s < 5; ++s) D[s][b] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      Dd[0][b] = Dd[1][b] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      // 16-bit lanes {row 2v, row 2v+1} of this N-block's column (K order of the B operand: element j = row 8g + j)
+      unsigned ru[4], du[4], r16[4], d16[4];
+      const unsigned selb = b ? 0x0c050c01u : 0x0c040c00u;  // {0, byte b of source 0, 0, byte b of source 1}
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        ru[v] = __builtin_amdgcn_perm(rr_[2 * v + 1], rr_[2 * v], selb);
+        du[v] = __builtin_amdgcn_perm(dr_[2 * v + 1], dr_[2 * v], selb);
+        r16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, ru[v]) - s2v{128, 128});
+        d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{128, 128});
+      }
+      unsigned t[4];
+#define PQA_MMA(Dacc, frag) Dacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[frag], B, Dacc, 0, 0, 0)
+      {  // means: r' and d', plus the next scale's input from the same operands
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(ru[v], 1152.0f);
+        const h8 B = frag_from(t[0], t[1], t[2], t[3]);
+        PQA_MMA(D[0][b], 0); PQA_MMA(Dd[0][b], 5); PQA_MMA(D[0][b], 1); PQA_MMA(Dd[0][b], 6); PQA_MMA(D[0][b], 2); PQA_MMA(Dd[0][b], 7);
+      }
+      {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(du[v], 1152.0f);
+        const h8 B = frag_from(t[0], t[1], t[2], t[3]);
+        PQA_MMA(D[1][b], 0); PQA_MMA(Dd[1][b], 5); PQA_MMA(D[1][b], 1); PQA_MMA(Dd[1][b], 6); PQA_MMA(D[1][b], 2); PQA_MMA(Dd[1][b], 7);
+      }
+      // squares and cross term: 16-bit integer products (exact), digits straight out of their bytes
+#pragma unroll
+      for (int s = 2; s < 5; ++s) {
+        unsigned q[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const s2v x = __builtin_bit_cast(s2v, s == 3 ? d16[v] : r16[v]);
+          const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
+          q[v] = __builtin_bit_cast(unsigned, (s2v)(x * y));
+        }
+        {  // low digit: byte 0 of each product, in [0, 255]
+#pragma unroll
+          for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_byte_of_halves(q[v], 0, 1024.0f);
+          const h8 B = frag_from(t[0], t[1], t[2], t[3]);
+          PQA_MMA(D[s][b], 3); PQA_MMA(D[s][b], 4);
+        }
+        {  // high digit: byte 1; the cross term is signed: bias by 64 * 256 first, take the bias off as f16
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            t[v] = s == 4 ? f16_pair_from_byte_of_halves(
+                                __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, q[v]) + s2v{0x4000, 0x4000}), 1, 1088.0f)
+                          : f16_pair_from_byte_of_halves(q[v], 1, 1024.0f);
+          const h8 B = frag_from(t[0], t[1], t[2], t[3]);
+          PQA_MMA(D[s][b], 0); PQA_MMA(D[s][b], 1); PQA_MMA(D[s][b], 2);
+        }
+      }
+#undef PQA_MMA
+    }
+    // upper tile -> LDS (registers 0,1 = rows 2g, 2g+1), lower tile's half parked
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      f2 in[2 * NREAD];
-      const f4* p = reinterpret_cast<const f4*>(&sv[s][rp][seg * 4]);
-#pragma unroll
-      for (int q = 0; q < NREAD; ++q) {
-        const f4 v = p[q];
-        in[2 * q] = f2{v.x, v.y};
-        in[2 * q + 1] = f2{v.z, v.w};
+      if (s < 2) {  // the means carry 2^19, the squares 2^11: bring them to the common 2^11 (exact)
+        D[s][0] *= kMfmaMuScale;
+        D[s][1] *= kMfmaMuScale;
       }
-      // tap-major order: the four outputs are independent chains, so consecutive v_pk_fma_f32 never
-      // depend on each other (a dependent pair costs an s_nop); each output still sums taps 0..N-1 in order
-#pragma unroll
-      for (int o = 0; o < 4; ++o) out[s][o] = f2{0.0f, 0.0f};
-#pragma unroll
-      for (int k = 0; k < N; ++k)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) out[s][o] = __builtin_elementwise_fma(a.taps.ht[k], in[o + k], out[s][o]);
-      __builtin_amdgcn_sched_barrier(0);  // one signal's 10 ds_read_b128 in flight at a time, not all 50
+      *reinterpret_cast<f4*>(&sv[s][g][col0]) = f4{D[s][0][0], D[s][0][1], D[s][1][0], D[s][1][1]};
+      park[pass][s] = f4{D[s][0][2], D[s][0][3], D[s][1][2], D[s][1][3]};
     }
-    const float sigma_nsq = 2.0f, eps = 1.0e-10f, sigma_max_inv = 4.0f / (255.0f * 255.0f);
-    // validity as 0/1 weights folded into the accumulation (an fma instead of an add): no branches, and
-    // out-of-image positions of edge tiles still hold finite values (mirrored real pixels)
-    const int gyA = y0 + 2 * rp;
-    const bool vrow[2] = {gyA < a.h, gyA + 1 < a.h};
-    f2 num2 = f2{0.0f, 0.0f}, den2 = f2{0.0f, 0.0f};
-    // the log terms of the sigma1_sq >= sigma_nsq branch are summed as the log of a product: per row of
-    // the pair the four columns' arguments (each in [2, 2^15]) are multiplied first, so the thread takes
-    // 6 v_log_f32 instead of 16 and needs no reciprocal for num's ratio (log a/b = log a - log b)
-    f2 pn = f2{1.0f, 1.0f}, qn = f2{1.0f, 1.0f}, pd = f2{1.0f, 1.0f};
+    *reinterpret_cast<f4*>(&sd[g][col0]) = f4{Dd[0][0][0], Dd[1][0][0], Dd[0][1][0], Dd[1][1][0]};
+    park_d[pass] = f4{Dd[0][0][1], Dd[1][0][1], Dd[0][1][1], Dd[1][1][1]};
+  }
+  __syncthreads();
+  vif_hstat<N, TW, ND>(a, &sv[0][0][0], &sd[0][0], red, fr, ty * a.tiles_x + tx, x0, y0);
+  // (vif_hstat ends with a workgroup barrier inside its block sum: every LDS read of the upper tile is done)
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const bool vcol = (x0 + seg * 4 + o) < a.w;
-      // the two rows of the pair go through the statistic together: every add / mul / fma is packed,
-      // only max / min / select / rcp / log are per element
-      const f2 mu1 = out[0][o], mu2 = out[1][o];
-      f2 s1 = out[2][o] - mu1 * mu1, s2 = out[3][o] - mu2 * mu2;
-      const f2 s12 = out[4][o] - mu1 * mu2;
-      s1 = f2{fmaxf(s1.x, 0.0f), fmaxf(s1.y, 0.0f)};
-      s2 = f2{fmaxf(s2.x, 0.0f), fmaxf(s2.y, 0.0f)};
-      // g = sigma12 / (sigma1_sq + eps): v_rcp_f32 plus one Newton correction -- exact 1.0 when the two
-      // are equal (identical frames), 2 FMAs instead of a full IEEE division
-      const f2 gden = s1 + f2{eps, eps};
-      const f2 grcp = f2{fast_rcp(gden.x), fast_rcp(gden.y)};
-      f2 g = s12 * grcp;
-      g = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, gden, s12), grcp, g);
-      f2 sv = s2 - g * s12;
-      // vif_statistic_s also has `if (sigma1_sq < eps) {g = 0; sv_sq = sigma2_sq; sigma1_sq = 0}` and
-      // `if (g < 0) {sv_sq = sigma2_sq; g = 0}`.  Both are dead for the result: the first implies
-      // sigma1_sq < sigma_nsq and the second implies sigma12 < 0, and each of those overrides num/den below.
-      if (s2.x < eps) { g.x = 0.0f; sv.x = 0.0f; }
-      if (s2.y < eps) { g.y = 0.0f; sv.y = 0.0f; }
-      sv = f2{fmaxf(sv.x, eps), fmaxf(sv.y, eps)};
-      // clamp g to [0, gain_limit] with one v_med3_f32: the upper bound is vif_enhn_gain_limit, the lower
-      // bound makes g*g = 0 when sigma12 < 0, i.e. num_val = log2(1) = 0 -- libvmaf's `if (sigma12 < 0) num_val = 0`
-      g = f2{__builtin_amdgcn_fmed3f(g.x, 0.0f, a.gain_limit), __builtin_amdgcn_fmed3f(g.y, 0.0f, a.gain_limit)};
-      const f2 svn = sv + f2{sigma_nsq, sigma_nsq};
-      // num_val = log2(1 + g^2 sigma1_sq / (sv_sq + sigma_nsq)) = log2(narg) - log2(svn)
-      const f2 narg = __builtin_elementwise_fma(g * g, s1, svn);
-      const f2 darg = __builtin_elementwise_fma(s1, f2{1.0f / sigma_nsq, 1.0f / sigma_nsq}, f2{1.0f, 1.0f});
-      const f2 low = __builtin_elementwise_fma(s2, f2{-sigma_max_inv, -sigma_max_inv}, f2{1.0f, 1.0f});
-      // validity and the branch choice as selects: out-of-image positions of edge tiles hold finite values
-      // (mirrored real pixels), they contribute a factor 1 and a weight 0
-      const bool vx = vcol && vrow[0], vy = vcol && vrow[1];
-      const bool hx = vx && !(s1.x < sigma_nsq), hy = vy && !(s1.y < sigma_nsq);
-      const bool lx = vx && (s1.x < sigma_nsq), ly = vy && (s1.y < sigma_nsq);
-      pn *= f2{hx ? narg.x : 1.0f, hy ? narg.y : 1.0f};
-      qn *= f2{hx ? svn.x : 1.0f, hy ? svn.y : 1.0f};
-      pd *= f2{hx ? darg.x : 1.0f, hy ? darg.y : 1.0f};
-      const f2 wl = f2{lx ? 1.0f : 0.0f, ly ? 1.0f : 0.0f};
-      num2 = __builtin_elementwise_fma(wl, low, num2);
-      den2 += wl;
-      __builtin_amdgcn_sched_barrier(0);  // two pixels' worth of temporaries live at a time
+  for (int pass = 0; pass < 2; ++pass) {
+    const int col0 = 64 * wave + 32 * pass + 2 * n;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) *reinterpret_cast<f4*>(&sv[s][g][col0]) = park[pass][s];
+    *reinterpret_cast<f4*>(&sd[g][col0]) = park_d[pass];
+  }
+  __syncthreads();
+  vif_hstat<N, TW, ND>(a, &sv[0][0][0], &sd[0][0], red, fr, (ty + 1) * a.tiles_x + tx, x0, y0 + TH);
+}
+
+// Host: the per-lane A fragments.  Row m = lane & 15 = 4 gg + i of the product is output row 8 (i >> 1) + 2 gg + (i & 1)
+// of the 16-row tile pair (see the kernel comment); K index k = 8 (lane >> 4) + j is input row k - 8 relative to the
+// pair's first row.  The decimation band puts even output row 2 gg of the upper (i = 0) / lower (i = 1) tile in
+// registers 0 / 1 and leaves 2, 3 empty.
+static bool build_atab(uint16_t* out /* [kAtabFrags][64][8] */) {
+  const Taps c17 = gaussian_taps(17), c9 = gaussian_taps(9);
+  bool exact = true;
+  for (int lane = 0; lane < 64; ++lane) {
+    const int m = lane & 15, gg = m >> 2, i = m & 3, kg = lane >> 4;
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * kg + j;
+      const int row = 8 * (i >> 1) + 2 * gg + (i & 1);
+      const int t17 = k - row;
+      const double c = (t17 >= 0 && t17 <= 16) ? (double)c17.f[t17] : 0.0;
+      const int t9 = k - (8 * i + 2 * gg + 4);
+      const double cd = (i < 2 && t9 >= 0 && t9 <= 8) ? (double)c9.f[t9] : 0.0;
+      const auto pieces = [&](double x, int n_pieces, int first_frag) {
+        double r = x;
+        for (int p = 0; p < n_pieces; ++p) {
+          const _Float16 h = (_Float16)r;
+          uint16_t bits;
+          memcpy(&bits, &h, 2);
+          out[((size_t)(first_frag + p) * 64 + lane) * 8 + j] = bits;
+          r -= (double)h;
+        }
+        return r;
+      };
+      if (pieces(c * 524288.0, 3, 0) != 0.0) exact = false;
+      pieces(c * 2048.0, 2, 3);
+      if (pieces(cd * 262144.0, 3, 5) != 0.0) exact = false;
     }
-    num = (num2.x + num2.y) + ((fast_log2(pn.x) - fast_log2(qn.x)) + (fast_log2(pn.y) - fast_log2(qn.y)));
-    den = (den2.x + den2.y) + (fast_log2(pd.x) + fast_log2(pd.y));
   }
-  const float part[2] = {num, den};
-  double v[2];
-  block_sum_f32<2>(part, v, red);
-  if (tid == 0) {
-    double* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * 2;
-    out[0] = v[0];
-    out[1] = v[1];
+  return exact;
+}
+
+static const uint4* device_atab() {
+  // one table per device, uploaded on first use (a few KB; the launchers themselves allocate nothing per call)
+  static std::mutex mu;
+  static const uint4* tabs[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!tabs[dev]) {
+    std::vector<uint16_t> h((size_t)kAtabFrags * 64 * 8);
+    if (!build_atab(h.data())) return nullptr;   // a tap that does not split exactly: keep the VALU kernel
+    void* d = nullptr;
+    if (hipMalloc(&d, h.size() * 2) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+    tabs[dev] = (const uint4*)d;
   }
+  return tabs[dev];
 }
 
 template <int N, int TW, int ND>
@@ -315,6 +587,44 @@ hipError_t launch_stat_n(hipStream_t stream, Elem elem, const VifStatArgs& a, in
     case ELEM_F32: hipLaunchKernelGGL((vif_stat_kernel<float, N, TW, ND>), grid, block, 0, stream, a); break;
   }
   return hipGetLastError();
+}
+
+// Scale 0, 8 bit: interior tile pairs on the matrix cores, border tiles on the VALU kernel (same partials, same planes).
+// Returns false when the geometry / alignment has no interior (the caller then runs the VALU kernel on every tile).
+bool launch_s0_split(hipStream_t stream, const VifStatArgs& base, int n_frames, hipError_t* err) {
+  constexpr int TW = 240, TH = kVifTileH;
+  {  // PQA_VIF_MFMA=0: every tile on the VALU kernel (A/B measurements, and the tests that compare the two paths)
+    const char* e = getenv("PQA_VIF_MFMA");
+    if (e && e[0] == '0') return false;
+  }
+  if (base.w < 2 * TW + 8 || base.h < 5 * TH) return false;
+  // 16-bit loads: even pitches and bases (any plane the library packs itself; odd caller pitches fall back)
+  if ((base.row_pitch_r | base.row_pitch_d | base.frame_pitch_r | base.frame_pitch_d) & 1) return false;
+  if (((uintptr_t)base.ref | (uintptr_t)base.dis) & 1) return false;
+  VifStatArgs a = base;
+  a.tx_lo = 1;                                   // input columns x0 - 8 .. x0 + 247 inside [0, w)
+  a.tx_hi = (base.w - (TW + 8)) / TW + 1;
+  a.ty_lo = 1;                                   // input rows y0 - 8 .. y0 + 23 inside [0, h): pairs (1,2), (3,4), ...
+  const int n_pairs = (base.h - 4 * TH) / (2 * TH) + 1;   // pair i starts at row 8 + 16 i and needs rows up to 8 + 16 i + 23
+  a.ty_hi = a.ty_lo + 2 * n_pairs;
+  if (a.tx_hi <= a.tx_lo || n_pairs <= 0) return false;
+  a.atab = device_atab();
+  if (!a.atab) return false;
+  const int n_int_pairs = (a.tx_hi - a.tx_lo) * n_pairs;
+  const int n_border = base.n_tiles - 2 * n_int_pairs;
+  // the matrix-core kernel: horizontal taps carry 2^-11, decimation taps 2^-18 (exact powers of two)
+  VifStatArgs m = a;
+  for (int k = 0; k < 17; ++k) m.taps.ht[k] = f2{a.taps.ht[k].x * kMfmaSqScale, a.taps.ht[k].y * kMfmaSqScale};
+  for (int k = 0; k < 9; ++k) m.taps.dt[k] = f2{a.taps.dt[k].x * kMfmaDecScale, a.taps.dt[k].y * kMfmaDecScale};
+  hipLaunchKernelGGL(vif_s0_mfma_kernel, dim3(n_int_pairs, n_frames), dim3(kBlock), 0, stream, m);
+  *err = hipGetLastError();
+  if (*err != hipSuccess) return true;
+  if (n_border > 0) {
+    a.edge_only = 1;
+    hipLaunchKernelGGL((vif_stat_kernel<uint8_t, 17, TW, 9, true>), dim3(n_border, n_frames), dim3(kBlock), 0, stream, a);
+    *err = hipGetLastError();
+  }
+  return true;
 }
 
 constexpr int kVifN[4] = {17, 9, 5, 3};
@@ -345,6 +655,10 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
   const Taps nxt = scale < 3 ? gaussian_taps(kVifN[scale + 1]) : Taps{};
   a.taps = tap_pairs(cur, kVifN[scale], scale < 3 ? &nxt : nullptr, scale < 3 ? kVifN[scale + 1] : 0);
   if (scale < 3 && (!a.dst_ref || !a.dst_dis)) return hipErrorInvalidValue;
+  if (scale == 0 && elem == ELEM_U8) {
+    hipError_t err = hipSuccess;
+    if (launch_s0_split(stream, a, n_frames, &err)) return err;
+  }
   switch (scale) {
     case 0: return launch_stat_n<17, 240, 9>(stream, elem, a, n_frames);
     case 1: return launch_stat_n<9, 248, 5>(stream, elem, a, n_frames);

@@ -338,3 +338,59 @@ def test_rccl_gather_of_device_records_with_one_rank(tmp_path):
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, str(_free_port())], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "rccl-one-rank ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+# ---- VIF scale 0 on the matrix cores (vif_s0_mfma_kernel) vs the VALU kernel and the oracle ------------------------
+@pytest.mark.parametrize("w,h", [(488, 40), (489, 41), (736, 48), (1000, 200), (1281, 721), (1920, 1080)])
+def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h):
+    """8-bit scale 0 runs its interior tiles through f16 MFMA (exact integer digit planes x three-piece taps) and the
+    border tiles through the VALU kernel.  Geometries from the smallest that has ONE interior tile pair (488 x 40) up
+    to 1080p, odd sizes included.  The two paths must agree far inside the oracle bar (the digit split is exact; only
+    the f32 accumulation order differs), PQA_VIF_MFMA=0 must really switch the path off, and a caller pitch the 16-bit
+    loads cannot take (odd) must fall back without a difference in results."""
+    import os
+    import torch
+    from pqa2_amd import synth
+    from pqa2_amd.engine import FeatureEngine
+    from pqa2_amd import _native as N
+    n = 2
+    refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+
+    def run(**kw):
+        with FeatureEngine(w, h, features=N.FEAT_VIF, **kw) as eng:
+            for i in range(n):
+                eng.submit(i, refs[i], diss[i])
+            return eng.collect(0, n)[:, :8]
+
+    old = os.environ.get("PQA_VIF_MFMA")
+    try:
+        os.environ["PQA_VIF_MFMA"] = "1"
+        mfma = run()
+        mfma101 = run(vif_border=N.VIF_BORDER_INTEGER)
+        os.environ["PQA_VIF_MFMA"] = "0"
+        valu = run()
+        valu101 = run(vif_border=N.VIF_BORDER_INTEGER)
+    finally:
+        if old is None:
+            os.environ.pop("PQA_VIF_MFMA", None)
+        else:
+            os.environ["PQA_VIF_MFMA"] = old
+    assert not np.array_equal(mfma.view(np.uint64), valu.view(np.uint64)), "the switch did not change the path"
+    rel = np.abs(mfma - valu) / np.abs(valu)
+    assert rel.max() < 2e-6, rel.max()
+    assert (np.abs(mfma101 - valu101) / np.abs(valu101)).max() < 2e-6
+    assert np.all(np.isfinite(mfma))
+    exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], 8)[:, :8]
+    assert (np.abs(mfma - exp) / np.abs(exp)).max() < REL_TOL
+    # device-resident clip with an ODD row pitch: 16-bit loads are not possible, the launcher must fall back
+    if w % 2 == 0:
+        pitch = w + 1
+        R = torch.zeros((n, h, pitch), dtype=torch.uint8, device="cuda")
+        D = torch.zeros((n, h, pitch), dtype=torch.uint8, device="cuda")
+        R[:, :, :w] = torch.from_numpy(np.stack([r[0] for r in refs])).cuda()
+        D[:, :, :w] = torch.from_numpy(np.stack([d[0] for d in diss])).cuda()
+        torch.cuda.synchronize()
+        with FeatureEngine(w, h, features=N.FEAT_VIF) as eng:
+            eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [pitch], [pitch * h])
+            odd = eng.collect(0, n)[:, :8]
+        assert np.array_equal(odd.view(np.uint64), valu.view(np.uint64))
