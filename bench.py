@@ -204,7 +204,12 @@ def main():
             cnt = {} if args.fixed_point & 1 else _kernel_counters(args.workload, "vif_stat_s0")
             per_frame = cnt.get("hbm_bytes_per_frame")
             traffic = int(per_frame * frames_per_launch) if per_frame else None
-            kname = ("vif_fixed_kernel" if args.fixed_point & 1 else "vif_stat_kernel") + f"<{'u8' if bpc == 8 else 'u16'},17,240,9>"
+            if args.fixed_point & 1:
+                kname = f"vif_fixed_kernel<{'u8' if bpc == 8 else 'u16'},17,240,9>"
+            elif bpc == 8:   # 8-bit: the matrix-core kernel, interior launch + edge launch, timed together
+                kname = "vif_s0_mfma_kernel<false> + <true> (interior + edge tile pairs; 17-tap vertical pass on f16 MFMA)"
+            else:
+                kname = "vif_stat_kernel<u16,17,240,9>"
             out["roofline"] = {"bound": "hbm", "kernel": kname + " (VIF scale 0 + fused decimation to scale 1)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -227,6 +232,15 @@ def main():
                     "measured_us_per_frame": round(meas_us, 2), "frac": round(floor_us / meas_us, 4),
                     "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk (v_pk_fma_f32 = 2 FMA per lane: 157 TFLOP/s)",
                     "source": cnt.get("valu_source")}
+            if bpc == 8 and not args.fixed_point:
+                # matrix-core share of the same launches: 108 v_mfma_f32_16x16x32_f16 (16384 FLOP each) per wave and
+                # 16-row tile pair, 4 waves per pair (csrc/vif.hip); dense f16 peak 2.5 PFLOP/s (MI355X_MICROARCH.md)
+                pairs = ((w + 239) // 240) * (((h + 7) // 8) // 2)
+                mf = pairs * 4 * 108 * 16384.0
+                out["roofline"]["mfma"] = {"flop_per_frame": mf, "achieved_tflops": round(mf * frames_per_launch / (avg_ms * 1e-3) / 1e12, 1),
+                                           "peak_tflops": 2500.0, "frac": round(mf * frames_per_launch / (avg_ms * 1e-3) / 2.5e15, 4),
+                                           "note": "the matrix pipe is shared with packed FP32 (tools/ubench/mfma_coissue.hip): the "
+                                                   "kernel's limiter is FP32 issue + this, not either alone"}
             out["kernel_ms_per_frame"] = {name: round(v["ms"] / max(1, v["frames"]), 5)
                                           for name, v in breakdown.items() if v["launches"]}
             out["kernel_ms_note"] = "from one extra untimed pass with every kernel event-timed (ms per frame)"
@@ -296,7 +310,7 @@ def kernel_source_hash() -> str:
     """sha256 over the sources of the dominant kernel: counters measured for another version of it are stale."""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("vif.hip", "pqa_device.h", "kernels.h"):
+    for f in ("vif.hip", "pqa_device.h", "kernels.h"):   # both scale-0 kernels live in vif.hip
         with open(os.path.join(ROOT, "pqa2_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]

@@ -77,20 +77,22 @@ struct VifStatArgs {
   float* dst_ref;
   float* dst_dis;
   int64_t dst_row_pitch_r, dst_frame_pitch_r, dst_row_pitch_d, dst_frame_pitch_d;
-  // Scale 0 of 8-bit clips splits the tile grid: the interior rectangle [tx_lo, tx_hi) x [ty_lo, ty_hi) (ty in pairs)
-  // goes to vif_s0_mfma_kernel, this kernel takes the border tiles only (edge_only; grid = number of border tiles).
-  int edge_only, tx_lo, tx_hi, ty_lo, ty_hi;
+  // Scale 0 of 8-bit clips splits the tile grid between kernels.  A launch either covers the rectangle
+  // [tx_lo, tx_hi) x [ty_lo, ty_hi) of a grid of tiles_x x grid_rows units or (EDGE variants) everything outside it.
+  // Units are tiles for vif_stat_kernel and vertically adjacent tile PAIRS (2p, 2p+1) for vif_s0_mfma_kernel.
+  int tx_lo, tx_hi, ty_lo, ty_hi, grid_rows;
   const uint4* atab;   // MFMA kernel: per-lane tap-matrix fragments (kAtabFrags x 64 lanes x 8 f16)
+  float lo_bias;       // MFMA kernel: -1024 * (sum of the two low-plane tap pieces over the 17-tap band)
   TapPairs taps;
 };
 
-// Border tile number e (0 .. n_border) -> tile id in the full grid: the rows above and below the interior rectangle
-// in full, then the left / right flanks of the rows beside it.
+// Border unit number e (0 .. n_border) -> unit id (row * tiles_x + column) in the full grid: the rows above and below
+// the rectangle in full, then the left / right flanks of the rows beside it.
 __device__ __forceinline__ int border_tile(int e, const VifStatArgs& a) {
   const int W = a.tiles_x, top = a.ty_lo * W;
   if (e < top) return e;
   e -= top;
-  const int tiles_y = a.n_tiles / W, bottom = (tiles_y - a.ty_hi) * W;
+  const int bottom = (a.grid_rows - a.ty_hi) * W;
   if (e < bottom) return a.ty_hi * W + e;
   e -= bottom;
   const int side = W - (a.tx_hi - a.tx_lo);
@@ -399,15 +401,22 @@ __device__ __forceinline__ unsigned f16_pair_from_byte_of_halves(unsigned x, int
   return __builtin_bit_cast(unsigned, v);
 }
 
+template <bool EDGE>
 __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArgs a) {
   constexpr int N = 17, TW = 240, ND = 9, TH = kVifTileH;
   __shared__ __attribute__((aligned(16))) f2 sv[5][TH / 2][kP2];
   __shared__ __attribute__((aligned(16))) f2 sd[TH / 2][kP2];
   __shared__ double red[8];
 
-  const int n_tx = a.tx_hi - a.tx_lo;
-  const int idx = xcd_remap(blockIdx.x, n_tx * ((a.ty_hi - a.ty_lo) >> 1));
-  const int tx = a.tx_lo + idx % n_tx, ty = a.ty_lo + 2 * (idx / n_tx);
+  int tx, ty;
+  if (EDGE) {   // pairs outside the interior rectangle: rows / columns are mirrored per lane in the loads below
+    const int u = border_tile(blockIdx.x, a);
+    tx = u % a.tiles_x; ty = 2 * (u / a.tiles_x);
+  } else {
+    const int n_tx = a.tx_hi - a.tx_lo;
+    const int idx = xcd_remap(blockIdx.x, n_tx * (a.ty_hi - a.ty_lo));
+    tx = a.tx_lo + idx % n_tx; ty = 2 * (a.ty_lo + idx / n_tx);
+  }
   const int fr = blockIdx.y;
   const uint8_t* __restrict__ ref = (const uint8_t*)a.ref + (int64_t)fr * a.frame_pitch_r;
   const uint8_t* __restrict__ dis = (const uint8_t*)a.dis + (int64_t)fr * a.frame_pitch_d;
@@ -428,22 +437,37 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int col0 = 64 * wave + 32 * pass + 2 * n;  // tile column (= LDS column) of N-block 0; N-block 1 is col0 + 1
-    const unsigned gx = (unsigned)(x0 - (N / 2) + col0);
-    const unsigned gy = (unsigned)(y0 - (N / 2) + 8 * g);
-    const unsigned off_r = gy * pitch_r + gx, off_d = gy * pitch_d + gx;
     unsigned rr_[8], dr_[8];  // rows 8g+j: the two columns in the low 16 bits
+    if (!EDGE) {
+      const unsigned gx = (unsigned)(x0 - (N / 2) + col0);
+      const unsigned gy = (unsigned)(y0 - (N / 2) + 8 * g);
+      const unsigned off_r = gy * pitch_r + gx, off_d = gy * pitch_d + gx;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      rr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, off_r, (unsigned)j * pitch_r, 0);
-      dr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, off_d, (unsigned)j * pitch_d, 0);
+      for (int j = 0; j < 8; ++j) {
+        rr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, off_r, (unsigned)j * pitch_r, 0);
+        dr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, off_d, (unsigned)j * pitch_d, 0);
+      }
+    } else {
+      // the border rule per lane (same folds as the VALU kernel): two byte loads per row, rows mirrored one by one
+      const unsigned gx0 = (unsigned)mirror_fold(x0 - (N / 2) + col0, a.w, a.fold_w);
+      const unsigned gx1 = (unsigned)mirror_fold(x0 - (N / 2) + col0 + 1, a.w, a.fold_w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned gy = (unsigned)mirror_fold(y0 - (N / 2) + 8 * g + j, a.h, a.fold_h);
+        const unsigned r0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx0, 0, 0) & 0xffu;
+        const unsigned r1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx1, 0, 0) & 0xffu;
+        const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx0, 0, 0) & 0xffu;
+        const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx1, 0, 0) & 0xffu;
+        rr_[j] = r0 | (r1 << 8);
+        dr_[j] = d0 | (d1 << 8);
+      }
     }
     f4 D[5][2], Dd[2][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int s = 0; s < 5; ++s) D[s][b] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-      Dd[0][b] = Dd[1][b] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
+    // Accumulators start in the FIRST product of each chain (srcC = a constant) instead of being cleared one by one.
+    // The low digit planes go in as 1024 + digit (no subtraction in the operand): every output row sees the full
+    // 17-tap band, so that adds the constant 1024 * sum(band) -- taken off by starting those chains at lo_bias
+    // (exact; smaller than the signal itself).
+    const f4 zero4 = f4{0.0f, 0.0f, 0.0f, 0.0f}, bias4 = f4{a.lo_bias, a.lo_bias, a.lo_bias, a.lo_bias};
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       // 16-bit lanes {row 2v, row 2v+1} of this N-block's column (K order of the B operand: element j = row 8g + j)
@@ -458,17 +482,18 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
       }
       unsigned t[4];
 #define PQA_MMA(Dacc, frag) Dacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[frag], B, Dacc, 0, 0, 0)
+#define PQA_MMA0(Dacc, frag, C0) Dacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[frag], B, C0, 0, 0, 0)
       {  // means: r' and d', plus the next scale's input from the same operands
 #pragma unroll
         for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(ru[v], 1152.0f);
         const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-        PQA_MMA(D[0][b], 0); PQA_MMA(Dd[0][b], 5); PQA_MMA(D[0][b], 1); PQA_MMA(Dd[0][b], 6); PQA_MMA(D[0][b], 2); PQA_MMA(Dd[0][b], 7);
+        PQA_MMA0(D[0][b], 0, zero4); PQA_MMA0(Dd[0][b], 5, zero4); PQA_MMA(D[0][b], 1); PQA_MMA(Dd[0][b], 6); PQA_MMA(D[0][b], 2); PQA_MMA(Dd[0][b], 7);
       }
       {
 #pragma unroll
         for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(du[v], 1152.0f);
         const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-        PQA_MMA(D[1][b], 0); PQA_MMA(Dd[1][b], 5); PQA_MMA(D[1][b], 1); PQA_MMA(Dd[1][b], 6); PQA_MMA(D[1][b], 2); PQA_MMA(Dd[1][b], 7);
+        PQA_MMA0(D[1][b], 0, zero4); PQA_MMA0(Dd[1][b], 5, zero4); PQA_MMA(D[1][b], 1); PQA_MMA(Dd[1][b], 6); PQA_MMA(D[1][b], 2); PQA_MMA(Dd[1][b], 7);
       }
       // squares and cross term: 16-bit integer products (exact), digits straight out of their bytes
 #pragma unroll
@@ -480,11 +505,11 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
           const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
           q[v] = __builtin_bit_cast(unsigned, (s2v)(x * y));
         }
-        {  // low digit: byte 0 of each product, in [0, 255]
+        {  // low digit: byte 0 of each product, in [0, 255], as f16 1024 + digit (bias in the accumulator's start value)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_byte_of_halves(q[v], 0, 1024.0f);
+          for (int v = 0; v < 4; ++v) t[v] = __builtin_amdgcn_perm(0x64646464u, q[v], 0x04020400u);
           const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-          PQA_MMA(D[s][b], 3); PQA_MMA(D[s][b], 4);
+          PQA_MMA0(D[s][b], 3, bias4); PQA_MMA(D[s][b], 4);
         }
         {  // high digit: byte 1; the cross term is signed: bias by 64 * 256 first, take the bias off as f16
 #pragma unroll
@@ -497,6 +522,7 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
         }
       }
 #undef PQA_MMA
+#undef PQA_MMA0
     }
     // upper tile -> LDS (registers 0,1 = rows 2g, 2g+1), lower tile's half parked
 #pragma unroll
@@ -529,6 +555,20 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
 // of the 16-row tile pair (see the kernel comment); K index k = 8 (lane >> 4) + j is input row k - 8 relative to the
 // pair's first row.  The decimation band puts even output row 2 gg of the upper (i = 0) / lower (i = 1) tile in
 // registers 0 / 1 and leaves 2, 3 empty.
+static double lo_band_sum() {  // sum over the 17 taps of the two f16 pieces of c * 2^11 (what the low digit planes see)
+  const Taps c17 = gaussian_taps(17);
+  double s = 0.0;
+  for (int t = 0; t < 17; ++t) {
+    double r = (double)c17.f[t] * 2048.0;
+    for (int p = 0; p < 2; ++p) {
+      const _Float16 h = (_Float16)r;
+      s += (double)h;
+      r -= (double)h;
+    }
+  }
+  return s;
+}
+
 static bool build_atab(uint16_t* out /* [kAtabFrags][64][8] */) {
   const Taps c17 = gaussian_taps(17), c9 = gaussian_taps(9);
   bool exact = true;
@@ -597,31 +637,43 @@ bool launch_s0_split(hipStream_t stream, const VifStatArgs& base, int n_frames, 
     const char* e = getenv("PQA_VIF_MFMA");
     if (e && e[0] == '0') return false;
   }
-  if (base.w < 2 * TW + 8 || base.h < 5 * TH) return false;
-  // 16-bit loads: even pitches and bases (any plane the library packs itself; odd caller pitches fall back)
+  const int tiles_y = base.n_tiles / base.tiles_x, pair_rows = tiles_y / 2;
+  if (pair_rows == 0) return false;
+  // 16-bit loads of the interior kernel: even pitches and bases (any plane the library packs itself; odd caller
+  // pitches fall back to the VALU kernel)
   if ((base.row_pitch_r | base.row_pitch_d | base.frame_pitch_r | base.frame_pitch_d) & 1) return false;
   if (((uintptr_t)base.ref | (uintptr_t)base.dis) & 1) return false;
-  VifStatArgs a = base;
-  a.tx_lo = 1;                                   // input columns x0 - 8 .. x0 + 247 inside [0, w)
-  a.tx_hi = (base.w - (TW + 8)) / TW + 1;
-  a.ty_lo = 1;                                   // input rows y0 - 8 .. y0 + 23 inside [0, h): pairs (1,2), (3,4), ...
-  const int n_pairs = (base.h - 4 * TH) / (2 * TH) + 1;   // pair i starts at row 8 + 16 i and needs rows up to 8 + 16 i + 23
-  a.ty_hi = a.ty_lo + 2 * n_pairs;
-  if (a.tx_hi <= a.tx_lo || n_pairs <= 0) return false;
-  a.atab = device_atab();
-  if (!a.atab) return false;
-  const int n_int_pairs = (a.tx_hi - a.tx_lo) * n_pairs;
-  const int n_border = base.n_tiles - 2 * n_int_pairs;
-  // the matrix-core kernel: horizontal taps carry 2^-11, decimation taps 2^-18 (exact powers of two)
-  VifStatArgs m = a;
-  for (int k = 0; k < 17; ++k) m.taps.ht[k] = f2{a.taps.ht[k].x * kMfmaSqScale, a.taps.ht[k].y * kMfmaSqScale};
-  for (int k = 0; k < 9; ++k) m.taps.dt[k] = f2{a.taps.dt[k].x * kMfmaDecScale, a.taps.dt[k].y * kMfmaDecScale};
-  hipLaunchKernelGGL(vif_s0_mfma_kernel, dim3(n_int_pairs, n_frames), dim3(kBlock), 0, stream, m);
-  *err = hipGetLastError();
-  if (*err != hipSuccess) return true;
-  if (n_border > 0) {
-    a.edge_only = 1;
-    hipLaunchKernelGGL((vif_stat_kernel<uint8_t, 17, TW, 9, true>), dim3(n_border, n_frames), dim3(kBlock), 0, stream, a);
+  VifStatArgs m = base;
+  m.atab = device_atab();
+  if (!m.atab) return false;
+  m.lo_bias = (float)(-1024.0 * lo_band_sum());
+  // horizontal taps carry 2^-11, decimation taps 2^-18 (exact powers of two)
+  for (int k = 0; k < 17; ++k) m.taps.ht[k] = f2{base.taps.ht[k].x * kMfmaSqScale, base.taps.ht[k].y * kMfmaSqScale};
+  for (int k = 0; k < 9; ++k) m.taps.dt[k] = f2{base.taps.dt[k].x * kMfmaDecScale, base.taps.dt[k].y * kMfmaDecScale};
+  // Pair p = tiles (2p, 2p+1), rows 16p .. 16p+15; it is INTERIOR when its 32 x 256 input window (rows 16p-8 .. 16p+23,
+  // columns 240tx-8 .. 240tx+247) lies inside the image: those pairs load 16 bits at a time with scalar row offsets.
+  m.grid_rows = pair_rows;
+  m.tx_lo = 1;
+  m.tx_hi = base.w >= 2 * TW + 8 ? (base.w - (TW + 8)) / TW + 1 : 1;
+  m.ty_lo = 1;
+  m.ty_hi = base.h >= 5 * TH ? (base.h - 3 * TH) / (2 * TH) + 1 : 1;
+  if (m.ty_hi > pair_rows) m.ty_hi = pair_rows;
+  if (m.tx_hi <= m.tx_lo || m.ty_hi <= m.ty_lo) m.tx_hi = m.tx_lo = m.ty_hi = m.ty_lo = 0;   // no interior at all
+  const int n_int = (m.tx_hi - m.tx_lo) * (m.ty_hi - m.ty_lo);
+  const int n_edge = base.tiles_x * pair_rows - n_int;
+  if (n_int > 0) {
+    hipLaunchKernelGGL(vif_s0_mfma_kernel<false>, dim3(n_int, n_frames), dim3(kBlock), 0, stream, m);
+    if ((*err = hipGetLastError()) != hipSuccess) return true;
+  }
+  if (n_edge > 0) {   // pairs that touch an image edge: the same kernel with per-lane mirrored byte loads
+    hipLaunchKernelGGL(vif_s0_mfma_kernel<true>, dim3(n_edge, n_frames), dim3(kBlock), 0, stream, m);
+    if ((*err = hipGetLastError()) != hipSuccess) return true;
+  }
+  if (tiles_y & 1) {  // an odd last tile row has no partner: VALU kernel on that row only
+    VifStatArgs a = base;
+    a.grid_rows = tiles_y;
+    a.tx_lo = 0; a.tx_hi = base.tiles_x; a.ty_lo = 0; a.ty_hi = tiles_y - 1;
+    hipLaunchKernelGGL((vif_stat_kernel<uint8_t, 17, TW, 9, true>), dim3(base.tiles_x, n_frames), dim3(kBlock), 0, stream, a);
     *err = hipGetLastError();
   }
   return true;

@@ -69,20 +69,28 @@ if pmc:
     import sys
     sys.path.insert(0, REPO)
     from bench import kernel_source_hash
-    pref = {"2160p": "unsigned char, 17", "1080p": "unsigned char, 17", "2160p10": "unsigned short, 17"}[a.workload]
-    k0 = next((k for k in pmc if k.startswith("vif_stat_kernel<" + pref) or k.startswith("vif_s0_mfma_kernel<" + pref)), None)
+    # scale 0 = every launch of launch_vif_stat(scale 0): 8-bit clips run vif_s0_mfma_kernel<false> (interior tile pairs)
+    # + <true> (pairs on an image edge) [+ the VALU kernel on an odd last tile row]; deeper samples the VALU kernel
+    if a.workload == "2160p10":
+        parts = [k for k in pmc if k.startswith("vif_stat_kernel<unsigned short, 17")]
+    else:
+        parts = [k for k in pmc if k.startswith("vif_s0_mfma_kernel<") or k.startswith("vif_stat_kernel<unsigned char, 17")]
+    k0 = max(parts, key=lambda k: pmc[k]["hbm_bytes_per_frame_corrected"]) if parts else None
     tj = os.path.join(root, "kernel_counters.json")
     cur = json.load(open(tj)) if os.path.exists(tj) else {}
     if k0:
-        e = {"kernel": k0, "hbm_bytes_per_frame": int(pmc[k0]["hbm_bytes_per_frame_corrected"]),
+        e = {"kernel": k0, "all_scale0_launches": parts,
+             "hbm_bytes_per_frame": int(sum(pmc[k]["hbm_bytes_per_frame_corrected"] for k in parts)),
              "measured_at_frames_per_launch": a.frames_per_launch, "src_hash": kernel_source_hash(),
              "traffic_source": f"profiles/{a.tag}_pmc.json (committed rocprofv3 --pmc passes, not this run)"}
         if a.sq_json:
-            sq = json.load(open(a.sq_json)).get(k0, {})
+            sqd = json.load(open(a.sq_json))
+            sq = sqd.get(k0, {})
             if sq:
-                e.update({"valu_insts_per_wave": round(sq["valu_per_wave"], 1), "waves_per_frame": int(round(sq["waves_per_launch"] / a.frames_per_launch)),
+                e.update({"valu_insts_per_wave": round(sq["valu_per_wave"], 1),
+                          "waves_per_frame": int(round(sq["waves_per_launch"] / a.frames_per_launch)),
                           "shader_clock_ghz": round(sq.get("clock_ghz", 2.0), 3),
-                          "valu_source": f"profiles/{a.tag}_sq_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, committed)"})
+                          "valu_source": f"profiles/{a.tag}_sq_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES of {k0}, committed)"})
         cur.setdefault(a.workload, {})["vif_stat_s0"] = e
         json.dump(cur, open(tj, "w"), indent=1)
 print("ok")
