@@ -224,13 +224,17 @@ def main():
             if cnt.get("valu_insts_per_wave"):
                 # issue floor = VALU instructions per wave x waves / (1024 SIMDs x one wave64 instruction per 4 clocks)
                 clk = cnt.get("shader_clock_ghz", 2.0)
-                floor_us = cnt["valu_insts_per_wave"] * cnt["waves_per_frame"] * 4.0 / (1024 * clk * 1e3)
+                wave_insts = cnt.get("valu_wave_insts_per_frame") or cnt["valu_insts_per_wave"] * cnt["waves_per_frame"]
+                floor_us = wave_insts * 4.0 / (1024 * clk * 1e3)
                 meas_us = 1e3 * avg_ms / frames_per_launch
                 out["roofline"]["valu"] = {
                     "valu_insts_per_wave": cnt["valu_insts_per_wave"], "waves_per_frame": cnt["waves_per_frame"],
+                    "valu_wave_insts_per_frame": int(wave_insts),
                     "shader_clock_ghz": clk, "issue_floor_us_per_frame": round(floor_us, 2),
                     "measured_us_per_frame": round(meas_us, 2), "frac": round(floor_us / meas_us, 4),
-                    "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk (v_pk_fma_f32 = 2 FMA per lane: 157 TFLOP/s)",
+                    "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk (v_pk_fma_f32 = 2 FMA per lane: 157 TFLOP/s); plain "
+                                 "(unpacked) VALU issues in 2 clk with >= 2 waves per SIMD and the 108 MFMAs per wave hold the pipe "
+                                 "16 clk each (profiles/r02a_ubench_*.txt), so this is a count-based floor, not a cycle model",
                     "source": cnt.get("valu_source")}
             if bpc == 8 and not args.fixed_point:
                 # matrix-core share of the same launches: 108 v_mfma_f32_16x16x32_f16 (16384 FLOP each) per wave and

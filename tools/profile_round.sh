@@ -12,18 +12,24 @@ OUT="$R/gpurun_out/prof_${TAG}"; RAW="/tmp/pqa_prof_${TAG}_${WL}"
 mkdir -p "$OUT" "$RAW"
 export TMPDIR=/tmp
 cd /tmp
-B="$R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-e2e"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -- python3 $B > "$OUT/${TAG}_bench_${WL}_under_rocprof.json" 2> "$RAW/stats.err"
-echo "stats pass done"
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$RAW/fetch" -- python3 $B > /dev/null 2> "$RAW/fetch.err"
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$RAW/write" -- python3 $B > /dev/null 2> "$RAW/write.err"
-echo "traffic passes done"
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d "$RAW/sqa" -- python3 $B > /dev/null 2> "$RAW/sqa.err"
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE -d "$RAW/sqb" -- python3 $B > /dev/null 2> "$RAW/sqb.err"
-echo "SQ passes done"
+say() { echo "$(date +%T) $*" | tee -a "$OUT/progress.log"; }
+T="timeout -k 10 150"
+# 96 frames = three full launches of 32 (frames per launch is then exact); short, so a profiler stall costs little
+FRAMES=96
+B="$R/bench.py --workload $WL --steps 2 --warmup 1 --frames $FRAMES --no-cpu-baseline --no-other-configs --no-e2e"
+$T rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -- python3 $B > "$OUT/${TAG}_bench_${WL}_under_rocprof.json" 2> "$RAW/stats.err"
+say "stats pass done"
+$T rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$RAW/fetch" -- python3 $B > /dev/null 2> "$RAW/fetch.err" || say "a counter pass failed or timed out (see above): its figures will be missing"
+say "fetch pass done"
+$T rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$RAW/write" -- python3 $B > /dev/null 2> "$RAW/write.err" || say "a counter pass failed or timed out (see above): its figures will be missing"
+say "traffic passes done"
+$T rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d "$RAW/sqa" -- python3 $B > /dev/null 2> "$RAW/sqa.err" || say "a counter pass failed or timed out (see above): its figures will be missing"
+say "SQ pass A done"
+$T rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE -d "$RAW/sqb" -- python3 $B > /dev/null 2> "$RAW/sqb.err" || say "a counter pass failed or timed out (see above): its figures will be missing"
+say "SQ passes done"
 BATCH=$(python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['config']['batch'])" "$OUT/${TAG}_bench_${WL}_under_rocprof.json")
 # frames per launch averaged over all launches (the last batch of a 300-frame clip is partial)
-FPL=$(python3 -c "import math; F=300; B=$BATCH; print(F / math.ceil(F / B))")
+FPL=$(python3 -c "import math; F=$FRAMES; B=$BATCH; print(F / math.ceil(F / B))")
 python3 "$R/tools/sq_counters.py" "$RAW/sqa" "$RAW/sqb" --json="$RAW/sq.json" > "$OUT/${TAG}_${WL}_sq_counters.txt"
 python3 "$R/tools/summarize_rocprof.py" --stats "$RAW/stats" --fetch "$RAW/fetch" --write "$RAW/write" --tag "${TAG}_${WL}" \
         --frames-per-launch "$FPL" --workload "$WL" --sq-json "$RAW/sq.json" --out "$OUT"

@@ -87,10 +87,14 @@ if pmc:
             sqd = json.load(open(a.sq_json))
             sq = sqd.get(k0, {})
             if sq:
+                have = [k for k in parts if k in sqd]
                 e.update({"valu_insts_per_wave": round(sq["valu_per_wave"], 1),
                           "waves_per_frame": int(round(sq["waves_per_launch"] / a.frames_per_launch)),
+                          # all scale-0 launches together: VALU wave-instructions per frame (sum over kernels of
+                          # instructions per wave x waves per frame)
+                          "valu_wave_insts_per_frame": int(sum(sqd[k]["valu_per_wave"] * sqd[k]["waves_per_launch"] for k in have) / a.frames_per_launch),
                           "shader_clock_ghz": round(sq.get("clock_ghz", 2.0), 3),
-                          "valu_source": f"profiles/{a.tag}_sq_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES of {k0}, committed)"})
+                          "valu_source": f"profiles/{a.tag}_sq_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES of the scale-0 launches, committed)"})
         cur.setdefault(a.workload, {})["vif_stat_s0"] = e
         json.dump(cur, open(tj, "w"), indent=1)
 print("ok")
