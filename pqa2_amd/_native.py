@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpqa_vmaf.so")
+# PQA_LIB_PATH: load another build of the SAME library (tools/build_variant.sh) -- A/B parity and timing runs only
+LIB_PATH = os.environ.get("PQA_LIB_PATH") or os.path.join(_HERE, "csrc", "libpqa_vmaf.so")
 
 PQA_OK, PQA_EINVAL, PQA_EDEVICE, PQA_ENOMEM, PQA_ECANCELLED, PQA_ESTATE = 0, -1, -2, -3, -4, -5
 FEAT_VIF, FEAT_ADM, FEAT_MOTION, FEAT_PSNR, FEAT_SSIM = 1, 2, 4, 8, 16

@@ -32,6 +32,7 @@ flips = 0
 worst_dv = 0.0
 worst_dv_small = 0.0
 worst_small_tag = None
+over_bar = []   # cases beyond the hard bars (5e-3 on a feature, 0.01 VMAF from 500k pixels): listed at the end, exit code 1
 mdl = M.load_model("vmaf_v0.6.1")
 
 
@@ -117,11 +118,15 @@ while time.time() - t0 < budget:
     # -- the f32 oracle itself jumps by 2e-2 against f64 when such a clip is cropped by one row.  They stay in the run
     # for finiteness and for the fixed-point bit-equality; their f32 bar is the size of such a jump.
     feat_bar = 5e-2 if kind in (2, 3) else 5e-3
-    assert rel.max() < feat_bar, ("f32 parity", tag, float(rel.max()), float(rel32.max()), np.unravel_index(rel.argmax(), rel.shape))
+    if not rel.max() < feat_bar:   # recorded, the run goes on: a long run should end with the full statistics
+        over_bar.append(("f32 parity", tag, float(rel.max()), float(rel32.max()), tuple(int(x) for x in np.unravel_index(rel.argmax(), rel.shape))))
+        print("OVER THE BAR:", over_bar[-1], flush=True)
     dv = np.minimum(np.abs(vmaf(got, w, h) - vmaf(exp, w, h)), np.abs(vmaf(got, w, h) - vmaf(exp32, w, h))).max()
     if px >= 500_000 and kind not in (2, 3):
         worst_dv = max(worst_dv, float(dv))
-        assert dv < 0.01, ("vmaf", tag, float(dv))
+        if not dv < 0.01:
+            over_bar.append(("vmaf", tag, float(dv)))
+            print("OVER THE BAR:", over_bar[-1], flush=True)
     elif kind not in (2, 3) and float(dv) > worst_dv_small:
         worst_dv_small, worst_small_tag = float(dv), tag
     assert abs(got[1, 16] - exp[1, 16]) < 2e-5 + 5e-6 * exp[1, 16], ("motion", tag, got[1, 16], exp[1, 16])
@@ -142,5 +147,10 @@ while time.time() - t0 < budget:
     if time.time() - last > 30:
         last = time.time()
         print(f"{n_cases} cases ok, worst f32 rel err {worst:.2e} (worst gpu/f32-oracle error ratio {ratio:.1f}), last {tag}", flush=True)
-print(f"fuzz ok: {n_cases} cases in {time.time() - t0:.0f} s, worst f32 rel err {worst:.2e}, worst ratio {ratio:.1f}, "
+print(f"fuzz {'ok' if not over_bar else 'done'}: {n_cases} cases in {time.time() - t0:.0f} s, worst f32 rel err {worst:.2e}, worst ratio {ratio:.1f}, "
       f"{flips} threshold-flip suspects, worst |dVMAF| {worst_dv:.4f} on frames >= 500k pixels (bar 0.01), {worst_dv_small:.4f} below (non-degenerate content; {worst_small_tag}); fixed-point mode bit-exact in every case")
+if over_bar:
+    print(f"{len(over_bar)} case(s) over a hard bar:")
+    for c in over_bar:
+        print("  ", c)
+    sys.exit(1)

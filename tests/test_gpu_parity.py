@@ -344,6 +344,8 @@ def test_random_geometry_sweep(oracle64, oracle32):
     ramps), every feature at once, against the oracle: tile seams, halo mirroring and masked lanes."""
     from pqa2_amd import _native as N
     from pqa2_amd.engine import sse_from_records
+    from pqa2_amd import model as M_
+    mdl_ = M_.load_model("vmaf_v0.6.1")
     rng = np.random.default_rng(20250418)
     sizes = [(16, 16), (17, 31), (61, 29), (63, 63), (121, 15 + 16), (239, 17), (241, 33), (253, 40), (130, 57),
              (rng.integers(16, 300), rng.integers(16, 120)), (rng.integers(16, 300), rng.integers(16, 120))]
@@ -376,6 +378,17 @@ def test_random_geometry_sweep(oracle64, oracle32):
         tol = max(REL_TOL, 4.0 * float(rel32.max()))
         print(f"\n{w}x{h} kind {int(kind)}: gpu-vs-f64 {rel.max():.2e}, f32-oracle-vs-f64 {rel32.max():.2e}")
         assert rel.max() < tol, (w, h, int(kind), float(rel.max()), float(rel32.max()), np.unravel_index(rel.argmax(), rel.shape))
+        # what the relative bar means in VMAF points, stated as an ABSOLUTE bound per frame size (DESIGN.md section 1:
+        # a decision taken at a 1e-7 margin flips in any f32 evaluation order, and one flipped coefficient weighs
+        # 1 / (number of coefficients)): 0.01 from 500 k pixels up (north_star's target, asserted at 1080p / 2160p in
+        # test_gpu_engine.py / test_gpu_configs.py), 0.05 from 20 k pixels, 0.25 below that
+        full64 = np.zeros((2, 24)); full64[:, :17] = exp
+        v_gpu = M_.score_frames(mdl_, M_.metrics_from_records(rec, w, h, "integer_"))["vmaf"]
+        v_f64 = M_.score_frames(mdl_, M_.metrics_from_records(full64, w, h, "integer_"))["vmaf"]
+        dv = float(np.abs(v_gpu - v_f64).max())
+        bound = 0.01 if w * h >= 500_000 else (0.05 if w * h >= 20_000 else 0.25)
+        print(f"   |dVMAF| {dv:.4f} (bound {bound} at {w * h} pixels)")
+        assert dv <= bound, (w, h, int(kind), dv)
         assert abs(rec[1, 16] - exp[1, 16]) < MOTION_ATOL + 5e-6 * exp[1, 16]
         sse = sse_from_records(rec)
         for p in range(3):
