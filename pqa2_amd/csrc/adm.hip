@@ -138,7 +138,6 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
   // ---- phase 2: horizontal DWT, decouple, CSF on row pairs ----------------------------------------
   // lane <-> halo'd column (62 of 64 used), wave + 4*round <-> row pair
   const float cos_1deg_sq = 0.99969541350954788f;  // cos(pi/180)^2
-  const float eps = 1e-30f;
   const int lcx = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // row pairs are per wave: row tests stay scalar
   const bool have = lcx < GW;
@@ -192,17 +191,15 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
         ld[(unsigned)cyB * (unsigned)a.ll_row_pitch_d + (unsigned)cx] = da.y;
       }
     }
-    // decouple: k = clamp(t / (o + eps), 0, 1) via v_rcp_f32 + one Newton step.  o + eps is either 1e-30
-    // (o == 0) or |o| >~ 1e-9 (an f32 DWT of bounded samples cannot produce a smaller non-zero value), so the
-    // reciprocal stays finite and no NaN can form.
-    const f2 e2 = splat(eps);
-    const f2 xh = oh + e2, xv = ov + e2, xd = od + e2;
-    const f2 rch = rcp2(xh), rcv = rcp2(xv), rcd = rcp2(xd);
-    f2 kh = th * rch, kv = tv * rcv, kd = td * rcd;
-    kh = clamp01_2(__builtin_elementwise_fma(__builtin_elementwise_fma(-kh, xh, th), rch, kh));
-    kv = clamp01_2(__builtin_elementwise_fma(__builtin_elementwise_fma(-kv, xv, tv), rcv, kv));
-    kd = clamp01_2(__builtin_elementwise_fma(__builtin_elementwise_fma(-kd, xd, td), rcd, kd));
-    f2 rh = kh * oh, rv = kv * ov, rd = kd * od;
+    // decouple: libvmaf computes k = clamp(t / (o + eps), 0, 1) and r = k * o.  In exact arithmetic that is
+    //   r = t  when t and o have the same sign and |t| <= |o|   (0 <= t/o <= 1)
+    //   r = o  when they have the same sign and |t| >  |o|     (t/o > 1 -> k = 1)
+    //   r = 0  when the signs differ or o == 0                 (t/o < 0 -> k = 0; o = 0: k * 0)
+    // i.e. r = median(0, t, o): ONE v_med3_f32 per coefficient and orientation, no division (the round-1 form was
+    // v_rcp_f32 + a Newton step + clamp + multiply: 7 instructions and a transcendental).  libvmaf's f32 r = fl(fl(t/o) * o)
+    // sits within one ulp of t in the first case; the median returns t itself, which is what the f64 oracle gets too.
+    const f2 z2 = splat(0.0f);
+    f2 rh = med3_2(z2, th, oh), rv = med3_2(z2, tv, ov), rd = med3_2(z2, td, od);
     const f2 ot_dp = __builtin_elementwise_fma(ov, tv, oh * th);
     const f2 o_mag_sq = __builtin_elementwise_fma(ov, ov, oh * oh), t_mag_sq = __builtin_elementwise_fma(tv, tv, th * th);
     const f2 lhs = ot_dp * ot_dp, rhs = splat(cos_1deg_sq) * o_mag_sq * t_mag_sq;

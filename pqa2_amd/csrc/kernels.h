@@ -37,6 +37,11 @@ inline int vif_tiles_y(int h) { return (h + kVifTileH - 1) / kVifTileH; }
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                            int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
                            MutPlaneRun next_ref, MutPlaneRun next_dis);
+// Scale 0 of 8-bit clips runs its vertical pass on the f16 matrix cores (vif_s0_mfma_kernel: one workgroup per pair of
+// vertically adjacent tiles; same partials, same next-scale planes).  That kernel reads a small per-device table of
+// tap-matrix fragments: upload it once per device BEFORE the first launch (pqa_create does).  Synchronous, idempotent.
+// Without the table -- or with PQA_VIF_MFMA=0, odd pitches / bases -- launch_vif_stat keeps the VALU kernel.
+hipError_t vif_mfma_prepare();
 
 // Fixed-point VIF (integer_vif.c arithmetic, vif_fixed.hip): same tiling; partials are [n_frames][tiles][8] int64
 // {num_log, den_log, x, x2, n_log, den_non_log, num_non_log, -}; next_ref / next_dis are u16 planes (w/2 x h/2).

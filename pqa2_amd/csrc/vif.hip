@@ -600,22 +600,16 @@ static bool build_atab(uint16_t* out /* [kAtabFrags][64][8] */) {
   return exact;
 }
 
+// One fragment table per device, uploaded by vif_mfma_prepare() (called from pqa_create: the launchers themselves never
+// allocate, so they stay capturable in a hipGraph).  Without a table the launcher keeps the VALU kernel.
+static std::mutex g_atab_mu;
+static const uint4* g_atab[64] = {};
+
 static const uint4* device_atab() {
-  // one table per device, uploaded on first use (a few KB; the launchers themselves allocate nothing per call)
-  static std::mutex mu;
-  static const uint4* tabs[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!tabs[dev]) {
-    std::vector<uint16_t> h((size_t)kAtabFrags * 64 * 8);
-    if (!build_atab(h.data())) return nullptr;   // a tap that does not split exactly: keep the VALU kernel
-    void* d = nullptr;
-    if (hipMalloc(&d, h.size() * 2) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
-    tabs[dev] = (const uint4*)d;
-  }
-  return tabs[dev];
+  std::lock_guard<std::mutex> lock(g_atab_mu);
+  return g_atab[dev];
 }
 
 template <int N, int TW, int ND>
@@ -646,7 +640,8 @@ bool launch_s0_split(hipStream_t stream, const VifStatArgs& base, int n_frames, 
   VifStatArgs m = base;
   m.atab = device_atab();
   if (!m.atab) return false;
-  m.lo_bias = (float)(-1024.0 * lo_band_sum());
+  static const float lo_bias = (float)(-1024.0 * lo_band_sum());
+  m.lo_bias = lo_bias;
   // horizontal taps carry 2^-11, decimation taps 2^-18 (exact powers of two)
   for (int k = 0; k < 17; ++k) m.taps.ht[k] = f2{base.taps.ht[k].x * kMfmaSqScale, base.taps.ht[k].y * kMfmaSqScale};
   for (int k = 0; k < 9; ++k) m.taps.dt[k] = f2{base.taps.dt[k].x * kMfmaDecScale, base.taps.dt[k].y * kMfmaDecScale};
@@ -685,6 +680,25 @@ constexpr int kVifTW[4] = {240, 248, 252, 252};
 }  // namespace
 
 int vif_tile_w(int scale) { return kVifTW[scale]; }
+
+hipError_t vif_mfma_prepare() {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipSuccess;   // no table: scale 0 stays on the VALU kernel on such a device
+  std::lock_guard<std::mutex> lock(g_atab_mu);
+  if (g_atab[dev]) return hipSuccess;
+  std::vector<uint16_t> h((size_t)kAtabFrags * 64 * 8);
+  if (!build_atab(h.data())) return hipSuccess;  // a tap that does not split exactly into f16 pieces: VALU kernel
+  void* d = nullptr;
+  if ((e = hipMalloc(&d, h.size() * 2)) != hipSuccess) return e;
+  if ((e = hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) {
+    (void)hipFree(d);
+    return e;
+  }
+  g_atab[dev] = (const uint4*)d;   // lives as long as the process (8 KB per device)
+  return hipSuccess;
+}
 
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                            int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
