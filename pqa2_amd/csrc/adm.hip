@@ -28,6 +28,7 @@ struct AdmArgs {
   int64_t row_pitch_r, frame_pitch_r, row_pitch_d, frame_pitch_d;
   int w, h, ow, oh, tiles_x, n_tiles;
   float inv_scale, gain_limit, rf_hv, rf_d;
+  float k_hv, k_d;  // rf / 30: CSF weight and the masking signal's 1/30 in one constant
   int left, top, right, bottom;  // cropped accumulation window in band coordinates
   float* ll_ref;
   float* ll_dis;
@@ -215,9 +216,10 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
     rd = f2{angA ? md.x : rd.x, angB ? md.y : rd.y};
     // CSF of the additive image; adm_cm_s sums the 3x3 boxes per orientation and then over
     // orientations -- summing over orientations first is the same value up to float rounding
-    const f2 ah = splat(a.rf_hv) * (th - rh), av = splat(a.rf_hv) * (tv - rv), ad = splat(a.rf_d) * (td - rd);
-    const float gA = (1.0f / 30.0f) * (fabsf(ah.x) + fabsf(av.x) + fabsf(ad.x));
-    const float gB = (1.0f / 30.0f) * (fabsf(ah.y) + fabsf(av.y) + fabsf(ad.y));
+    // (|rf_hv a_h| + |rf_hv a_v| + |rf_d a_d|) / 30 with the constants folded: k_hv (|a_h| + |a_v|) + k_d |a_d|
+    const f2 ah = th - rh, av = tv - rv, ad = td - rd;
+    const float gA = fmaf(a.k_d, fabsf(ad.x), a.k_hv * (fabsf(ah.x) + fabsf(av.x)));
+    const float gB = fmaf(a.k_d, fabsf(ad.y), a.k_hv * (fabsf(ah.y) + fabsf(av.y)));
     const bool wA = iA && col_win && cyA >= a.top && cyA < a.bottom;
     const bool wB = iB && col_win && cyB >= a.top && cyB < a.bottom;
     const f2 mw = f2{wA ? 1.0f : 0.0f, wB ? 1.0f : 0.0f};
@@ -225,11 +227,11 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
     xs[k][0] = rh * splat(a.rf_hv);   // signed; |.| is applied where it is used
     xs[k][1] = rv * splat(a.rf_hv);
     xs[k][2] = rd * splat(a.rf_d);
-    const f2 uh = oh * splat(a.rf_hv), uv = ov * splat(a.rf_hv), ud = od * splat(a.rf_d);
-    const f2 qh = mw * (uh * uh), qv = mw * (uv * uv), qd = mw * (ud * ud);
-    den_h = f2{fmaf(qh.x, fabsf(uh.x), den_h.x), fmaf(qh.y, fabsf(uh.y), den_h.y)};
-    den_v = f2{fmaf(qv.x, fabsf(uv.x), den_v.x), fmaf(qv.y, fabsf(uv.y), den_v.y)};
-    den_d = f2{fmaf(qd.x, fabsf(ud.x), den_d.x), fmaf(qd.y, fabsf(ud.y), den_d.y)};
+    // denominator: sum |rf o|^3 = rf^3 sum |o|^3 -- the CSF factor leaves the loop (applied to the tile sum below)
+    const f2 qh = mw * (oh * oh), qv = mw * (ov * ov), qd = mw * (od * od);
+    den_h = f2{fmaf(qh.x, fabsf(oh.x), den_h.x), fmaf(qh.y, fabsf(oh.y), den_h.y)};
+    den_v = f2{fmaf(qv.x, fabsf(ov.x), den_v.x), fmaf(qv.y, fabsf(ov.y), den_v.y)};
+    den_d = f2{fmaf(qd.x, fabsf(od.x), den_d.x), fmaf(qd.y, fabsf(od.y), den_d.y)};
     if (have) {
       G[lcyA][lcx] = vA ? gA : 0.0f;
       G[lcyA + 1][lcx] = vB ? gB : 0.0f;
@@ -279,8 +281,9 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
       }
     }
   }
+  const float rf3_hv = a.rf_hv * a.rf_hv * a.rf_hv, rf3_d = a.rf_d * a.rf_d * a.rf_d;
   const float part[6] = {num_h.x + num_h.y, num_v.x + num_v.y, num_d.x + num_d.y,
-                         den_h.x + den_h.y, den_v.x + den_v.y, den_d.x + den_d.y};
+                         rf3_hv * (den_h.x + den_h.y), rf3_hv * (den_v.x + den_v.y), rf3_d * (den_d.x + den_d.y)};
   double v[6];
   block_sum_f32<6>(part, v, red);
   if (tid == 0) {
@@ -320,6 +323,8 @@ hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun r
   a.inv_scale = inv_scale; a.gain_limit = gain_limit;
   a.rf_hv = 1.0f / dwt_quant_step(scale, 1);
   a.rf_d = 1.0f / dwt_quant_step(scale, 2);
+  a.k_hv = a.rf_hv / 30.0f;
+  a.k_d = a.rf_d / 30.0f;
   const double border = 0.1;  // ADM_BORDER_FACTOR
   a.left = (int)(a.ow * border - 0.5);
   a.top = (int)(a.oh * border - 0.5);
