@@ -222,6 +222,10 @@ def score_frames(model: VmafModel, metrics: dict, enable_transform: bool = False
     out = dict(metrics)
     out["vmaf"] = main.predict(X, enable_transform)
     if len(model.models) > 1:
+        # BOOTSTRAP collections (vmaf_b_v0.6.3): entry 0 scores `vmaf`, the other 20 give the spread.  PARITY UNPINNED:
+        # the four statistic NAMES follow libvmaf's log keys as remembered (vmaf_bagging, vmaf_stddev, vmaf_ci_p95_lo/hi);
+        # whether libvmaf uses the population std (ddof 0, as here) and linear-interpolated 2.5 / 97.5 percentiles is a
+        # VERIFY item -- the reference holds no bootstrap output to check against.
         boots = np.stack([m.predict(X, enable_transform) for m in model.models[1:]], 0)
         out["vmaf_bagging"] = boots.mean(0)
         out["vmaf_stddev"] = boots.std(0)

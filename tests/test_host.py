@@ -261,3 +261,19 @@ def test_bootstrap_collection_and_pooling_keys():
     np.testing.assert_array_equal(single, out["vmaf"])
     log = report.build_vmaf_log(out, 30.0)
     assert set(log["pooled_metrics"]["vmaf_bagging"]) == {"min", "max", "mean", "harmonic_mean"}
+
+
+def test_committed_kernel_counters_match_the_kernel_source():
+    """bench.py's `roofline.traffic` / `roofline.valu` come from committed rocprofv3 --pmc passes (profiles/
+    kernel_counters.json) and are dropped when the dominant kernel's source has changed since.  This guards the repo
+    state: after editing csrc/vif.hip (or pqa_device.h / kernels.h) re-run `tools/profile_round.sh <tag> 2160p` on the
+    GPU box and copy gpurun_out/prof_<tag>/* into profiles/."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "kernel_counters.json")))
+    e = d["2160p"]["vif_stat_s0"]
+    assert e["src_hash"] == bench.kernel_source_hash(), "profiles/kernel_counters.json is stale: re-run tools/profile_round.sh"
+    assert e["hbm_bytes_per_frame"] > 2 * 3840 * 2160 and e["valu_wave_insts_per_frame"] > 0
+    assert os.path.exists(os.path.join(root, e["traffic_source"].split(" ")[0]))
