@@ -111,7 +111,9 @@ constexpr int kP2 = 258;  // LDS row pitch in float2: == 2 (mod 32) -> conflict-
 // Phases 1b (fused decimation), 2 (horizontal pass) and 3 (statistic + tile partial) of one TW x 8 tile whose
 // vertical-pass results are in LDS: sv[signal][row pair][column] = {row 2p, row 2p+1}, sd[even row][column] =
 // {ref, dis}.  Shared by the VALU kernel (vif_stat_kernel) and the matrix-core kernel (vif_s0_mfma_kernel).
-template <int N, int TW, int ND>
+// FULL: every pixel of the tile lies inside the image (interior tile pairs of the matrix-core kernel): the validity
+// masks of edge tiles drop out.
+template <int N, int TW, int ND, bool FULL = false>
 __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* [5][TH/2][kP2] */,
                                           const f2* sd /* [TH/2][kP2] */, double* red, int fr, int tile, int x0, int y0) {
   constexpr int R = N / 2, TH = kVifTileH, NSEG = TW / 4, NRP = TH / 2;
@@ -127,7 +129,7 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
       const int item = tid + round * kBlock;
       const int oc = item & 127, orow = item >> 7;  // 128 slots per row, TW/2 of them used
       const int gx = ox0 + oc, gy = oy0 + orow;
-      if (oc < TW / 2 && gx < ow && gy < oh) {
+      if (oc < TW / 2 && (FULL || (gx < ow && gy < oh))) {
         f2 acc = f2{0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < ND; ++k) acc = __builtin_elementwise_fma(a.taps.dt[k], sd[orow * kP2 + 2 * oc + (R - RD) + k], acc);
@@ -173,7 +175,7 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
     // validity as 0/1 weights folded into the accumulation (an fma instead of an add): no branches, and
     // out-of-image positions of edge tiles still hold finite values (mirrored real pixels)
     const int gyA = y0 + 2 * rp;
-    const bool vrow[2] = {gyA < a.h, gyA + 1 < a.h};
+    const bool vrow[2] = {FULL || gyA < a.h, FULL || gyA + 1 < a.h};
     f2 num2 = f2{0.0f, 0.0f}, den2 = f2{0.0f, 0.0f};
     // the log terms of the sigma1_sq >= sigma_nsq branch are summed as the log of a product: per row of
     // the pair the four columns' arguments (each in [2, 2^15]) are multiplied first, so the thread takes
@@ -181,7 +183,7 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
     f2 pn = f2{1.0f, 1.0f}, qn = f2{1.0f, 1.0f}, pd = f2{1.0f, 1.0f};
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      const bool vcol = (x0 + seg * 4 + o) < a.w;
+      const bool vcol = FULL || (x0 + seg * 4 + o) < a.w;
       // the two rows of the pair go through the statistic together: every add / mul / fma is packed,
       // only max / min / select / rcp / log are per element
       const f2 mu1 = out[0][o], mu2 = out[1][o];
@@ -199,8 +201,10 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
       // vif_statistic_s also has `if (sigma1_sq < eps) {g = 0; sv_sq = sigma2_sq; sigma1_sq = 0}` and
       // `if (g < 0) {sv_sq = sigma2_sq; g = 0}`.  Both are dead for the result: the first implies
       // sigma1_sq < sigma_nsq and the second implies sigma12 < 0, and each of those overrides num/den below.
-      if (s2.x < eps) { g.x = 0.0f; sv.x = 0.0f; }
-      if (s2.y < eps) { g.y = 0.0f; sv.y = 0.0f; }
+      // Its third override, `if (sigma2_sq < eps) {g = 0; sv_sq = 0}`, changes nothing measurable either: with
+      // sigma2_sq < 1e-10 Cauchy-Schwarz bounds |sigma12| <= sqrt(sigma1_sq * 1e-10), so g^2 sigma1_sq <= 1e-10 next to
+      // sv_sq + 2 in the log's argument, and sv_sq = sigma2_sq - g sigma12 lies within 1e-10 of 0 and is raised to eps
+      // by the max below in both forms.  (Round 1 kept it as two compares and four selects per pixel pair.)
       sv = f2{fmaxf(sv.x, eps), fmaxf(sv.y, eps)};
       // clamp g to [0, gain_limit] with one v_med3_f32: the upper bound is vif_enhn_gain_limit, the lower
       // bound makes g*g = 0 when sigma12 < 0, i.e. num_val = log2(1) = 0 -- libvmaf's `if (sigma12 < 0) num_val = 0`
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
     park_d[pass] = f4{Dd[0][0][1], Dd[1][0][1], Dd[0][1][1], Dd[1][1][1]};
   }
   __syncthreads();
-  vif_hstat<N, TW, ND>(a, &sv[0][0][0], &sd[0][0], red, fr, ty * a.tiles_x + tx, x0, y0);
+  vif_hstat<N, TW, ND, !EDGE>(a, &sv[0][0][0], &sd[0][0], red, fr, ty * a.tiles_x + tx, x0, y0);
   // (vif_hstat ends with a workgroup barrier inside its block sum: every LDS read of the upper tile is done)
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
     *reinterpret_cast<f4*>(&sd[g][col0]) = park_d[pass];
   }
   __syncthreads();
-  vif_hstat<N, TW, ND>(a, &sv[0][0][0], &sd[0][0], red, fr, (ty + 1) * a.tiles_x + tx, x0, y0 + TH);
+  vif_hstat<N, TW, ND, !EDGE>(a, &sv[0][0][0], &sd[0][0], red, fr, (ty + 1) * a.tiles_x + tx, x0, y0 + TH);
 }
 
 // Host: the per-lane A fragments.  Row m = lane & 15 = 4 gg + i of the product is output row 8 (i >> 1) + 2 gg + (i & 1)
