@@ -384,11 +384,15 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef short s2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-constexpr int kAtabFrags = 8;  // 0-2: c*2^19 pieces (means, high digits)  3-4: c*2^11 pieces (low digits)  5-7: c'*2^18 (decimation)
+// fragments in the table: 0-2: c*2^19 pieces (means, high digits)  3-4: c*2^11 pieces (8-bit low digits, base 256)
+// 5-7: c'*2^18 pieces (decimation)  8-9: c*2^9 pieces (10-bit low digits, base 1024)
+constexpr int kAtabFrags = 10;
 constexpr float kMfmaSqScale = 1.0f / 2048.0f;       // 2^-11: squares / cross term after the vertical pass
 constexpr float kMfmaMuScale = 1.0f / 256.0f;        // 2^-19 / 2^-11: the means carry 2^8 more
 constexpr float kMfmaDecScale = 1.0f / 262144.0f;    // 2^-18: decimation planes
 
+// v_bfi_b32: bits of `a` where the mask is set, bits of `b` elsewhere
+__device__ __forceinline__ unsigned bfi32(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
 __device__ __forceinline__ h8 frag_from(unsigned a, unsigned b, unsigned c, unsigned d) {
   return __builtin_bit_cast(h8, u4v{a, b, c, d});
 }
@@ -405,9 +409,15 @@ __device__ __forceinline__ unsigned f16_pair_from_byte_of_halves(unsigned x, int
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <bool EDGE>
+// T = uint8_t: 8-bit samples as described above.  T = uint16_t: 10-bit samples (libvmaf: x = v / 4 - 128 = (v - 512) / 4):
+// v - 512 is one exact f16 plane, the squares (<= 2^18) and the cross term split into base-1024 digits (hi <= 256,
+// lo < 1024: both exact in f16) from 32-bit products; the low planes use pieces of c * 2^9, the powers of four of the
+// sample scale go into the horizontal taps.  12-bit clips (squares of 22 bits: three digits) stay on the VALU kernel.
+template <typename T, bool EDGE>
 __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArgs a) {
   constexpr int N = 17, TW = 240, ND = 9, TH = kVifTileH;
+  constexpr bool W16 = sizeof(T) == 2;
+  constexpr int ES = (int)sizeof(T);
   __shared__ __attribute__((aligned(16))) f2 sv[5][TH / 2][kP2];
   __shared__ __attribute__((aligned(16))) f2 sd[TH / 2][kP2];
   __shared__ double red[8];
@@ -422,48 +432,63 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
     tx = a.tx_lo + idx % n_tx; ty = 2 * (a.ty_lo + idx / n_tx);
   }
   const int fr = blockIdx.y;
-  const uint8_t* __restrict__ ref = (const uint8_t*)a.ref + (int64_t)fr * a.frame_pitch_r;
-  const uint8_t* __restrict__ dis = (const uint8_t*)a.dis + (int64_t)fr * a.frame_pitch_d;
+  const T* __restrict__ ref = (const T*)a.ref + (int64_t)fr * a.frame_pitch_r;
+  const T* __restrict__ dis = (const T*)a.dis + (int64_t)fr * a.frame_pitch_d;
   const int x0 = tx * TW, y0 = ty * TH;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
-  const unsigned pitch_r = (unsigned)a.row_pitch_r, pitch_d = (unsigned)a.row_pitch_d;
+  const unsigned pitch_r = (unsigned)a.row_pitch_r * ES, pitch_d = (unsigned)a.row_pitch_d * ES;  // bytes
   const auto rsrc_r = make_rsrc(ref, (unsigned)a.h * pitch_r);
   const auto rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d);
+  constexpr int FRAG_LO0 = 3;   // first of the two low-digit-plane fragments (c * 2^11 pieces at 8 bit, c * 2^9 at 10 bit)
 
   // tap-matrix fragments of this lane (A operand: row = lane & 15, K group = lane >> 4)
-  h8 A[kAtabFrags];
+  h8 A[8];   // slots 3, 4 hold the low-digit pieces of this sample type
 #pragma unroll
-  for (int f = 0; f < kAtabFrags; ++f) A[f] = __builtin_bit_cast(h8, a.atab[f * 64 + lane]);
+  for (int f = 0; f < 8; ++f) A[f] = __builtin_bit_cast(h8, a.atab[((W16 && (f == 3 || f == 4)) ? f + 5 : f) * 64 + lane]);
 
   f4 park[2][5];   // lower tile's rows {2g, 2g+1} x columns {2n, 2n+1} per pass and signal
   f4 park_d[2];    // lower tile's decimation row g: {ref, dis} x 2 columns
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int col0 = 64 * wave + 32 * pass + 2 * n;  // tile column (= LDS column) of N-block 0; N-block 1 is col0 + 1
-    unsigned rr_[8], dr_[8];  // rows 8g+j: the two columns in the low 16 bits
+    unsigned rr_[8], dr_[8];  // rows 8g+j: the two columns (8 bit: in the low 16 bits; 16 bit: low / high half)
     if (!EDGE) {
       const unsigned gx = (unsigned)(x0 - (N / 2) + col0);
       const unsigned gy = (unsigned)(y0 - (N / 2) + 8 * g);
-      const unsigned off_r = gy * pitch_r + gx, off_d = gy * pitch_d + gx;
+      const unsigned off_r = gy * pitch_r + gx * ES, off_d = gy * pitch_d + gx * ES;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        rr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, off_r, (unsigned)j * pitch_r, 0);
-        dr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, off_d, (unsigned)j * pitch_d, 0);
+        if (W16) {
+          rr_[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc_r, off_r, (unsigned)j * pitch_r, 0);
+          dr_[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc_d, off_d, (unsigned)j * pitch_d, 0);
+        } else {
+          rr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, off_r, (unsigned)j * pitch_r, 0);
+          dr_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, off_d, (unsigned)j * pitch_d, 0);
+        }
       }
     } else {
-      // the border rule per lane (same folds as the VALU kernel): two byte loads per row, rows mirrored one by one
-      const unsigned gx0 = (unsigned)mirror_fold(x0 - (N / 2) + col0, a.w, a.fold_w);
-      const unsigned gx1 = (unsigned)mirror_fold(x0 - (N / 2) + col0 + 1, a.w, a.fold_w);
+      // the border rule per lane (same folds as the VALU kernel): two loads per row, rows mirrored one by one
+      const unsigned gx0 = (unsigned)mirror_fold(x0 - (N / 2) + col0, a.w, a.fold_w) * ES;
+      const unsigned gx1 = (unsigned)mirror_fold(x0 - (N / 2) + col0 + 1, a.w, a.fold_w) * ES;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned gy = (unsigned)mirror_fold(y0 - (N / 2) + 8 * g + j, a.h, a.fold_h);
-        const unsigned r0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx0, 0, 0) & 0xffu;
-        const unsigned r1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx1, 0, 0) & 0xffu;
-        const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx0, 0, 0) & 0xffu;
-        const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx1, 0, 0) & 0xffu;
-        rr_[j] = r0 | (r1 << 8);
-        dr_[j] = d0 | (d1 << 8);
+        if (W16) {
+          const unsigned r0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, gy * pitch_r + gx0, 0, 0);
+          const unsigned r1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, gy * pitch_r + gx1, 0, 0);
+          const unsigned d0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, gy * pitch_d + gx0, 0, 0);
+          const unsigned d1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, gy * pitch_d + gx1, 0, 0);
+          rr_[j] = r0 | (r1 << 16);
+          dr_[j] = d0 | (d1 << 16);
+        } else {
+          const unsigned r0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx0, 0, 0) & 0xffu;
+          const unsigned r1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx1, 0, 0) & 0xffu;
+          const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx0, 0, 0) & 0xffu;
+          const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx1, 0, 0) & 0xffu;
+          rr_[j] = r0 | (r1 << 8);
+          dr_[j] = d0 | (d1 << 8);
+        }
       }
     }
     f4 D[5][2], Dd[2][2];
@@ -476,53 +501,83 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
     for (int b = 0; b < 2; ++b) {
       // 16-bit lanes {row 2v, row 2v+1} of this N-block's column (K order of the B operand: element j = row 8g + j)
       unsigned ru[4], du[4], r16[4], d16[4];
-      const unsigned selb = b ? 0x0c050c01u : 0x0c040c00u;  // {0, byte b of source 0, 0, byte b of source 1}
+      // 8 bit: {0, byte b of source 0, 0, byte b of source 1};  16 bit: {half b of source 0, half b of source 1}
+      const unsigned selb = W16 ? (b ? 0x07060302u : 0x05040100u) : (b ? 0x0c050c01u : 0x0c040c00u);
+      constexpr short MID = W16 ? 512 : 128;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         ru[v] = __builtin_amdgcn_perm(rr_[2 * v + 1], rr_[2 * v], selb);
         du[v] = __builtin_amdgcn_perm(dr_[2 * v + 1], dr_[2 * v], selb);
-        r16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, ru[v]) - s2v{128, 128});
-        d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{128, 128});
+        r16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, ru[v]) - s2v{MID, MID});
+        d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{MID, MID});
       }
       unsigned t[4];
 #define PQA_MMA(Dacc, frag) Dacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[frag], B, Dacc, 0, 0, 0)
 #define PQA_MMA0(Dacc, frag, C0) Dacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[frag], B, C0, 0, 0, 0)
-      {  // means: r' and d', plus the next scale's input from the same operands
+      {  // means: r' and d' (sample - mid-grey, exact in f16), plus the next scale's input from the same operands
 #pragma unroll
-        for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(ru[v], 1152.0f);
+        for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(ru[v], 1024.0f + MID);
         const h8 B = frag_from(t[0], t[1], t[2], t[3]);
         PQA_MMA0(D[0][b], 0, zero4); PQA_MMA0(Dd[0][b], 5, zero4); PQA_MMA(D[0][b], 1); PQA_MMA(Dd[0][b], 6); PQA_MMA(D[0][b], 2); PQA_MMA(Dd[0][b], 7);
       }
       {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(du[v], 1152.0f);
+        for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(du[v], 1024.0f + MID);
         const h8 B = frag_from(t[0], t[1], t[2], t[3]);
         PQA_MMA0(D[1][b], 0, zero4); PQA_MMA0(Dd[1][b], 5, zero4); PQA_MMA(D[1][b], 1); PQA_MMA(Dd[1][b], 6); PQA_MMA(D[1][b], 2); PQA_MMA(Dd[1][b], 7);
       }
-      // squares and cross term: 16-bit integer products (exact), digits straight out of their bytes
+      // squares and cross term: integer products (exact), digits straight out of their bits
 #pragma unroll
       for (int s = 2; s < 5; ++s) {
-        unsigned q[4];
+        if (!W16) {
+          unsigned q[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const s2v x = __builtin_bit_cast(s2v, s == 3 ? d16[v] : r16[v]);
-          const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
-          q[v] = __builtin_bit_cast(unsigned, (s2v)(x * y));
-        }
-        {  // low digit: byte 0 of each product, in [0, 255], as f16 1024 + digit (bias in the accumulator's start value)
+          for (int v = 0; v < 4; ++v) {
+            const s2v x = __builtin_bit_cast(s2v, s == 3 ? d16[v] : r16[v]);
+            const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
+            q[v] = __builtin_bit_cast(unsigned, (s2v)(x * y));
+          }
+          {  // low digit: byte 0 of each 16-bit product, in [0, 255], as f16 1024 + digit (bias in the accumulator's start)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) t[v] = __builtin_amdgcn_perm(0x64646464u, q[v], 0x04020400u);
-          const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-          PQA_MMA0(D[s][b], 3, bias4); PQA_MMA(D[s][b], 4);
-        }
-        {  // high digit: byte 1; the cross term is signed: bias by 64 * 256 first, take the bias off as f16
+            for (int v = 0; v < 4; ++v) t[v] = __builtin_amdgcn_perm(0x64646464u, q[v], 0x04020400u);
+            const h8 B = frag_from(t[0], t[1], t[2], t[3]);
+            PQA_MMA0(D[s][b], FRAG_LO0, bias4); PQA_MMA(D[s][b], FRAG_LO0 + 1);
+          }
+          {  // high digit: byte 1; the cross term is signed: bias by 64 * 256 first, take the bias off as f16
 #pragma unroll
-          for (int v = 0; v < 4; ++v)
-            t[v] = s == 4 ? f16_pair_from_byte_of_halves(
-                                __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, q[v]) + s2v{0x4000, 0x4000}), 1, 1088.0f)
-                          : f16_pair_from_byte_of_halves(q[v], 1, 1024.0f);
-          const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-          PQA_MMA(D[s][b], 0); PQA_MMA(D[s][b], 1); PQA_MMA(D[s][b], 2);
+            for (int v = 0; v < 4; ++v)
+              t[v] = s == 4 ? f16_pair_from_byte_of_halves(
+                                  __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, q[v]) + s2v{0x4000, 0x4000}), 1, 1088.0f)
+                            : f16_pair_from_byte_of_halves(q[v], 1, 1024.0f);
+            const h8 B = frag_from(t[0], t[1], t[2], t[3]);
+            PQA_MMA(D[s][b], 0); PQA_MMA(D[s][b], 1); PQA_MMA(D[s][b], 2);
+          }
+        } else {
+          // 10 bit: |v - 512| <= 512, products of 20 bits: 32-bit multiplies on the sign-extended halves; the cross
+          // term gets 256 * 1024 added so that its high digit (>> 10, in [0, 512]) is unsigned like the squares'
+          unsigned lo_[4], hi_[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const unsigned xs = s == 3 ? d16[v] : r16[v], ys = s == 2 ? r16[v] : d16[v];
+            const int x0_ = (int)(short)(xs & 0xffffu), x1_ = (int)xs >> 16;
+            const int y0_ = (int)(short)(ys & 0xffffu), y1_ = (int)ys >> 16;
+            const int add = s == 4 ? (256 << 10) : 0;
+            const unsigned p0 = (unsigned)(x0_ * y0_ + add), p1 = (unsigned)(x1_ * y1_ + add);
+            // {1024 + lo(p1), 1024 + lo(p0)} and {1024 + hi(p1), 1024 + hi(p0)} as f16 bit patterns (v_bfi_b32)
+            const unsigned l = bfi32(0x03ff0000u, p1 << 16, bfi32(0x3ffu, p0, 0x64006400u));
+            const unsigned hgh = bfi32(0x03ff0000u, p1 << 6, bfi32(0x3ffu, p0 >> 10, 0x64006400u));
+            lo_[v] = l;
+            const float hb = s == 4 ? 1280.0f : 1024.0f;
+            hi_[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, hgh) - h2{(_Float16)hb, (_Float16)hb});
+          }
+          {
+            const h8 B = frag_from(lo_[0], lo_[1], lo_[2], lo_[3]);
+            PQA_MMA0(D[s][b], FRAG_LO0, bias4); PQA_MMA(D[s][b], FRAG_LO0 + 1);
+          }
+          {
+            const h8 B = frag_from(hi_[0], hi_[1], hi_[2], hi_[3]);
+            PQA_MMA(D[s][b], 0); PQA_MMA(D[s][b], 1); PQA_MMA(D[s][b], 2);
+          }
         }
       }
 #undef PQA_MMA
@@ -559,11 +614,11 @@ __global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArg
 // of the 16-row tile pair (see the kernel comment); K index k = 8 (lane >> 4) + j is input row k - 8 relative to the
 // pair's first row.  The decimation band puts even output row 2 gg of the upper (i = 0) / lower (i = 1) tile in
 // registers 0 / 1 and leaves 2, 3 empty.
-static double lo_band_sum() {  // sum over the 17 taps of the two f16 pieces of c * 2^11 (what the low digit planes see)
+static double lo_band_sum(double scale) {  // sum over the 17 taps of the two f16 pieces of c * scale (what the low digit planes see)
   const Taps c17 = gaussian_taps(17);
   double s = 0.0;
   for (int t = 0; t < 17; ++t) {
-    double r = (double)c17.f[t] * 2048.0;
+    double r = (double)c17.f[t] * scale;
     for (int p = 0; p < 2; ++p) {
       const _Float16 h = (_Float16)r;
       s += (double)h;
@@ -599,6 +654,7 @@ static bool build_atab(uint16_t* out /* [kAtabFrags][64][8] */) {
       if (pieces(c * 524288.0, 3, 0) != 0.0) exact = false;
       pieces(c * 2048.0, 2, 3);
       if (pieces(cd * 262144.0, 3, 5) != 0.0) exact = false;
+      pieces(c * 512.0, 2, 8);
     }
   }
   return exact;
@@ -629,7 +685,7 @@ hipError_t launch_stat_n(hipStream_t stream, Elem elem, const VifStatArgs& a, in
 
 // Scale 0, 8 bit: interior tile pairs on the matrix cores, border tiles on the VALU kernel (same partials, same planes).
 // Returns false when the geometry / alignment has no interior (the caller then runs the VALU kernel on every tile).
-bool launch_s0_split(hipStream_t stream, const VifStatArgs& base, int n_frames, hipError_t* err) {
+bool launch_s0_split(hipStream_t stream, bool ten_bit, const VifStatArgs& base, int n_frames, hipError_t* err) {
   constexpr int TW = 240, TH = kVifTileH;
   {  // PQA_VIF_MFMA=0: every tile on the VALU kernel (A/B measurements, and the tests that compare the two paths)
     const char* e = getenv("PQA_VIF_MFMA");
@@ -637,20 +693,22 @@ bool launch_s0_split(hipStream_t stream, const VifStatArgs& base, int n_frames, 
   }
   const int tiles_y = base.n_tiles / base.tiles_x, pair_rows = tiles_y / 2;
   if (pair_rows == 0) return false;
-  // 16-bit loads of the interior kernel: even pitches and bases (any plane the library packs itself; odd caller
-  // pitches fall back to the VALU kernel)
+  // the interior kernel loads two columns at a time (16 bits of an 8-bit plane, 32 bits of a 10-bit plane): even element
+  // pitches, bases aligned to that (any plane the library packs itself; other caller layouts fall back to the VALU kernel)
   if ((base.row_pitch_r | base.row_pitch_d | base.frame_pitch_r | base.frame_pitch_d) & 1) return false;
-  if (((uintptr_t)base.ref | (uintptr_t)base.dis) & 1) return false;
+  if (((uintptr_t)base.ref | (uintptr_t)base.dis) & (ten_bit ? 3 : 1)) return false;
   VifStatArgs m = base;
   m.atab = device_atab();
   if (!m.atab) return false;
-  static const float lo_bias = (float)(-1024.0 * lo_band_sum());
-  m.lo_bias = lo_bias;
-  // horizontal taps carry 2^-11, decimation taps 2^-18 (exact powers of two)
-  for (int k = 0; k < 17; ++k) m.taps.ht[k] = f2{base.taps.ht[k].x * kMfmaSqScale, base.taps.ht[k].y * kMfmaSqScale};
-  for (int k = 0; k < 9; ++k) m.taps.dt[k] = f2{base.taps.dt[k].x * kMfmaDecScale, base.taps.dt[k].y * kMfmaDecScale};
+  static const float lo_bias8 = (float)(-1024.0 * lo_band_sum(2048.0)), lo_bias10 = (float)(-1024.0 * lo_band_sum(512.0));
+  m.lo_bias = ten_bit ? lo_bias10 : lo_bias8;
+  // the vertical pass leaves 2^11 x the 8-bit signals (2^13 x the 10-bit ones: 2^9 from the tap pieces, 4^2 from the
+  // sample scale) and 2^18 (2^20) x the next scale's input: exact powers of two, folded into the horizontal taps
+  const float sq = ten_bit ? kMfmaSqScale * 0.25f : kMfmaSqScale, dec = ten_bit ? kMfmaDecScale * 0.25f : kMfmaDecScale;
+  for (int k = 0; k < 17; ++k) m.taps.ht[k] = f2{base.taps.ht[k].x * sq, base.taps.ht[k].y * sq};
+  for (int k = 0; k < 9; ++k) m.taps.dt[k] = f2{base.taps.dt[k].x * dec, base.taps.dt[k].y * dec};
   // Pair p = tiles (2p, 2p+1), rows 16p .. 16p+15; it is INTERIOR when its 32 x 256 input window (rows 16p-8 .. 16p+23,
-  // columns 240tx-8 .. 240tx+247) lies inside the image: those pairs load 16 bits at a time with scalar row offsets.
+  // columns 240tx-8 .. 240tx+247) lies inside the image: those pairs load two columns at a time with scalar row offsets.
   m.grid_rows = pair_rows;
   m.tx_lo = 1;
   m.tx_hi = base.w >= 2 * TW + 8 ? (base.w - (TW + 8)) / TW + 1 : 1;
@@ -661,18 +719,21 @@ bool launch_s0_split(hipStream_t stream, const VifStatArgs& base, int n_frames, 
   const int n_int = (m.tx_hi - m.tx_lo) * (m.ty_hi - m.ty_lo);
   const int n_edge = base.tiles_x * pair_rows - n_int;
   if (n_int > 0) {
-    hipLaunchKernelGGL(vif_s0_mfma_kernel<false>, dim3(n_int, n_frames), dim3(kBlock), 0, stream, m);
+    if (ten_bit) hipLaunchKernelGGL((vif_s0_mfma_kernel<uint16_t, false>), dim3(n_int, n_frames), dim3(kBlock), 0, stream, m);
+    else hipLaunchKernelGGL((vif_s0_mfma_kernel<uint8_t, false>), dim3(n_int, n_frames), dim3(kBlock), 0, stream, m);
     if ((*err = hipGetLastError()) != hipSuccess) return true;
   }
-  if (n_edge > 0) {   // pairs that touch an image edge: the same kernel with per-lane mirrored byte loads
-    hipLaunchKernelGGL(vif_s0_mfma_kernel<true>, dim3(n_edge, n_frames), dim3(kBlock), 0, stream, m);
+  if (n_edge > 0) {   // pairs that touch an image edge: the same kernel with per-lane mirrored loads
+    if (ten_bit) hipLaunchKernelGGL((vif_s0_mfma_kernel<uint16_t, true>), dim3(n_edge, n_frames), dim3(kBlock), 0, stream, m);
+    else hipLaunchKernelGGL((vif_s0_mfma_kernel<uint8_t, true>), dim3(n_edge, n_frames), dim3(kBlock), 0, stream, m);
     if ((*err = hipGetLastError()) != hipSuccess) return true;
   }
   if (tiles_y & 1) {  // an odd last tile row has no partner: VALU kernel on that row only
     VifStatArgs a = base;
     a.grid_rows = tiles_y;
     a.tx_lo = 0; a.tx_hi = base.tiles_x; a.ty_lo = 0; a.ty_hi = tiles_y - 1;
-    hipLaunchKernelGGL((vif_stat_kernel<uint8_t, 17, TW, 9, true>), dim3(base.tiles_x, n_frames), dim3(kBlock), 0, stream, a);
+    if (ten_bit) hipLaunchKernelGGL((vif_stat_kernel<uint16_t, 17, TW, 9, true>), dim3(base.tiles_x, n_frames), dim3(kBlock), 0, stream, a);
+    else hipLaunchKernelGGL((vif_stat_kernel<uint8_t, 17, TW, 9, true>), dim3(base.tiles_x, n_frames), dim3(kBlock), 0, stream, a);
     *err = hipGetLastError();
   }
   return true;
@@ -725,9 +786,11 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
   const Taps nxt = scale < 3 ? gaussian_taps(kVifN[scale + 1]) : Taps{};
   a.taps = tap_pairs(cur, kVifN[scale], scale < 3 ? &nxt : nullptr, scale < 3 ? kVifN[scale + 1] : 0);
   if (scale < 3 && (!a.dst_ref || !a.dst_dis)) return hipErrorInvalidValue;
-  if (scale == 0 && elem == ELEM_U8) {
+  // scale 0 of 8-bit and 10-bit clips: vertical pass on the matrix cores (10 bit is recognised by its sample scale 1/4;
+  // 12-bit clips and every deeper scale run the VALU kernel)
+  if (scale == 0 && (elem == ELEM_U8 || (elem == ELEM_U16 && inv_scale == 0.25f))) {
     hipError_t err = hipSuccess;
-    if (launch_s0_split(stream, a, n_frames, &err)) return err;
+    if (launch_s0_split(stream, elem == ELEM_U16, a, n_frames, &err)) return err;
   }
   switch (scale) {
     case 0: return launch_stat_n<17, 240, 9>(stream, elem, a, n_frames);

@@ -341,8 +341,9 @@ def test_rccl_gather_of_device_records_with_one_rank(tmp_path):
 
 
 # ---- VIF scale 0 on the matrix cores (vif_s0_mfma_kernel) vs the VALU kernel and the oracle ------------------------
-@pytest.mark.parametrize("w,h", [(488, 40), (489, 41), (736, 48), (1000, 200), (1281, 721), (1920, 1080)])
-def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h):
+@pytest.mark.parametrize("w,h,bpc", [(488, 40, 8), (489, 41, 8), (736, 48, 8), (1000, 200, 8), (1281, 721, 8), (1920, 1080, 8),
+                                     (64, 48, 10), (489, 41, 10), (1000, 200, 10), (1920, 1080, 10)])
+def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
     """8-bit scale 0 runs its interior tiles through f16 MFMA (exact integer digit planes x three-piece taps) and the
     border tiles through the VALU kernel.  Geometries from the smallest that has ONE interior tile pair (488 x 40) up
     to 1080p, odd sizes included.  The two paths must agree far inside the oracle bar (the digit split is exact; only
@@ -354,10 +355,16 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h):
     from pqa2_amd.engine import FeatureEngine
     from pqa2_amd import _native as N
     n = 2
-    refs, diss = synth.make_clip(w, h, n, 8, chroma=False)
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
+    if bpc > 8:   # the extremes of the sample range in both clips: digit planes at their limits (0 -> -512, 1023 -> 511)
+        refs[0][0][:4, :8] = 0; diss[0][0][:4, :8] = 1023
+        refs[1][0][-3:, -9:] = 1023; diss[1][0][-3:, -9:] = 1023
+    else:
+        refs[0][0][:4, :8] = 0; diss[0][0][:4, :8] = 255
+        refs[1][0][-3:, -9:] = 255; diss[1][0][-3:, -9:] = 255
 
     def run(**kw):
-        with FeatureEngine(w, h, features=N.FEAT_VIF, **kw) as eng:
+        with FeatureEngine(w, h, bit_depth=bpc, features=N.FEAT_VIF, **kw) as eng:
             for i in range(n):
                 eng.submit(i, refs[i], diss[i])
             return eng.collect(0, n)[:, :8]
@@ -380,17 +387,19 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h):
     assert rel.max() < 2e-6, rel.max()
     assert (np.abs(mfma101 - valu101) / np.abs(valu101)).max() < 2e-6
     assert np.all(np.isfinite(mfma))
-    exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], 8)[:, :8]
+    exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc)[:, :8]
     assert (np.abs(mfma - exp) / np.abs(exp)).max() < REL_TOL
     # device-resident clip with an ODD row pitch: 16-bit loads are not possible, the launcher must fall back
     if w % 2 == 0:
         pitch = w + 1
-        R = torch.zeros((n, h, pitch), dtype=torch.uint8, device="cuda")
-        D = torch.zeros((n, h, pitch), dtype=torch.uint8, device="cuda")
-        R[:, :, :w] = torch.from_numpy(np.stack([r[0] for r in refs])).cuda()
-        D[:, :, :w] = torch.from_numpy(np.stack([d[0] for d in diss])).cuda()
+        es = 1 if bpc <= 8 else 2
+        tdt = torch.uint8 if bpc <= 8 else torch.int16
+        R = torch.zeros((n, h, pitch), dtype=tdt, device="cuda")
+        D = torch.zeros((n, h, pitch), dtype=tdt, device="cuda")
+        R[:, :, :w] = torch.from_numpy(np.stack([r[0] for r in refs]).view(np.int16 if bpc > 8 else np.uint8)).cuda()
+        D[:, :, :w] = torch.from_numpy(np.stack([d[0] for d in diss]).view(np.int16 if bpc > 8 else np.uint8)).cuda()
         torch.cuda.synchronize()
-        with FeatureEngine(w, h, features=N.FEAT_VIF) as eng:
-            eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [pitch], [pitch * h])
+        with FeatureEngine(w, h, bit_depth=bpc, features=N.FEAT_VIF) as eng:
+            eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [pitch * es], [pitch * h * es])
             odd = eng.collect(0, n)[:, :8]
         assert np.array_equal(odd.view(np.uint64), valu.view(np.uint64))
