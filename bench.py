@@ -206,8 +206,9 @@ def main():
             traffic = int(per_frame * frames_per_launch) if per_frame else None
             if args.fixed_point & 1:
                 kname = f"vif_fixed_kernel<{'u8' if bpc == 8 else 'u16'},17,240,9>"
-            elif bpc == 8:   # 8-bit: the matrix-core kernel, interior launch + edge launch, timed together
-                kname = "vif_s0_mfma_kernel<false> + <true> (interior + edge tile pairs; 17-tap vertical pass on f16 MFMA)"
+            elif bpc <= 10:   # the matrix-core kernel, interior launch + edge launch, timed together
+                kname = (f"vif_s0_mfma_kernel<{'u8' if bpc == 8 else 'u16'},false> + <..,true> (interior + edge tile pairs; "
+                         f"17-tap vertical pass on f16 MFMA)")
             else:
                 kname = "vif_stat_kernel<u16,17,240,9>"
             out["roofline"] = {"bound": "hbm", "kernel": kname + " (VIF scale 0 + fused decimation to scale 1)",
@@ -236,7 +237,7 @@ def main():
                                  "(unpacked) VALU issues in 2 clk with >= 2 waves per SIMD and the 108 MFMAs per wave hold the pipe "
                                  "16 clk each (profiles/r02a_ubench_*.txt), so this is a count-based floor, not a cycle model",
                     "source": cnt.get("valu_source")}
-            if bpc == 8 and not args.fixed_point:
+            if bpc <= 10 and not args.fixed_point:
                 # matrix-core share of the same launches: 108 v_mfma_f32_16x16x32_f16 (16384 FLOP each) per wave and
                 # 16-row tile pair, 4 waves per pair (csrc/vif.hip); dense f16 peak 2.5 PFLOP/s (MI355X_MICROARCH.md)
                 pairs = ((w + 239) // 240) * (((h + 7) // 8) // 2)

@@ -71,10 +71,8 @@ if pmc:
     from bench import kernel_source_hash
     # scale 0 = every launch of launch_vif_stat(scale 0): 8-bit clips run vif_s0_mfma_kernel<false> (interior tile pairs)
     # + <true> (pairs on an image edge) [+ the VALU kernel on an odd last tile row]; deeper samples the VALU kernel
-    if a.workload == "2160p10":
-        parts = [k for k in pmc if k.startswith("vif_stat_kernel<unsigned short, 17")]
-    else:
-        parts = [k for k in pmc if k.startswith("vif_s0_mfma_kernel<") or k.startswith("vif_stat_kernel<unsigned char, 17")]
+    ty = "unsigned short" if a.workload == "2160p10" else "unsigned char"
+    parts = [k for k in pmc if k.startswith(f"vif_s0_mfma_kernel<{ty}") or k.startswith(f"vif_stat_kernel<{ty}, 17")]
     k0 = max(parts, key=lambda k: pmc[k]["hbm_bytes_per_frame_corrected"]) if parts else None
     tj = os.path.join(root, "kernel_counters.json")
     cur = json.load(open(tj)) if os.path.exists(tj) else {}
