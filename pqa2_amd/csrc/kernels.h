@@ -34,9 +34,19 @@ inline int vif_tiles_y(int h) { return (h + kVifTileH - 1) / kVifTileH; }
 // border101: 0 = vif_tools.c border rule (high edge repeated), 1 = integer_vif.c padding (reflect-101).
 // For scale < 3 the same launch also produces the next scale's input (fused decimation): the planes are
 // filtered with the next scale's kernel and even samples kept -> next_ref / next_dis, (w/2 x h/2) f32.
+// `motion` (scale 0 only, nullable): let the matrix-core kernel produce the motion SAD partials too -- one double per
+// VIF tile, [n_frames][tiles] -- from the reference frames it reads anyway; prev0 / prev0_row_pitch (elements) describe the
+// reference luma before the run's first frame (null: that frame's motion is 0), as for launch_motion.  *fused_motion
+// reports whether that happened (it does not when the VALU kernel had to be used or PQA_FUSE_MOTION=0).
+struct VifMotionFusion {
+  const void* prev0;
+  int64_t prev0_row_pitch;
+  double* partials;
+};
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                            int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
-                           MutPlaneRun next_ref, MutPlaneRun next_dis);
+                           MutPlaneRun next_ref, MutPlaneRun next_dis, const VifMotionFusion* motion = nullptr,
+                           bool* fused_motion = nullptr);
 // Scale 0 of 8-bit clips runs its vertical pass on the f16 matrix cores (vif_s0_mfma_kernel: one workgroup per pair of
 // vertically adjacent tiles; same partials, same next-scale planes).  That kernel reads a small per-device table of
 // tap-matrix fragments: upload it once per device BEFORE the first launch (pqa_create does).  Synchronous, idempotent.

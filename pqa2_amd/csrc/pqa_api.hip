@@ -354,6 +354,21 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   };
   const PlaneRun rYs = k > 1 ? sub(rY) : rY, dYs = k > 1 ? sub(dY) : dY;
 
+  // motion: reference luma in front of the batch (caller's halo, the armed halo, or the last frame of the previous batch)
+  const void* p0 = prev;
+  int64_t p0_pitch = prev_pitch_bytes;
+  if (feat & PQA_FEAT_MOTION) {
+    if (!p0 && (c->halo_armed || (c->have_last && c->last_index == first - 1))) {
+      p0 = c->last_luma;
+      p0_pitch = c->last_luma_pitch;
+    }
+    if (p0 && p0_pitch % es) return fail(c, PQA_EINVAL, "halo pitch is not a multiple of the sample size");
+  }
+  // the matrix-core VIF kernel can produce the motion SAD from the reference frames it reads anyway (csrc/vif.hip)
+  const bool try_fuse = (feat & PQA_FEAT_MOTION) && (feat & PQA_FEAT_VIF) && !c->vif_fixed && !c->motion_fixed && k == 1 &&
+                        c->cfg.bit_depth <= 10;
+  bool motion_fused = false;
+
   if ((feat & PQA_FEAT_VIF) && sp_n > 0 && c->vif_fixed) {
     PlaneRun cr = rYs, cd = dYs;
     Elem ce = c->elem;
@@ -391,9 +406,10 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       }
       {
         ProfScope ps(c, s, sp_n, st);
+        const VifMotionFusion mo{p0, p0 ? p0_pitch / es : 0, c->motion_part};
         HIPCHK(c, launch_vif_stat(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
                                   (float)c->cfg.vif_enhn_gain_limit, c->cfg.vif_border == PQA_VIF_BORDER_INTEGER,
-                                  c->vif_part[s], nr, nd));
+                                  c->vif_part[s], nr, nd, (s == 0 && try_fuse) ? &mo : nullptr, s == 0 ? &motion_fused : nullptr));
       }
       if (s < 3) {
         Level& L = c->vif_lv[s + 1];
@@ -453,14 +469,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       }
     }
   }
-  if (feat & PQA_FEAT_MOTION) {
-    const void* p0 = prev;
-    int64_t p0_pitch = prev_pitch_bytes;
-    if (!p0 && (c->halo_armed || (c->have_last && c->last_index == first - 1))) {
-      p0 = c->last_luma;
-      p0_pitch = c->last_luma_pitch;
-    }
-    if (p0 && p0_pitch % es) return fail(c, PQA_EINVAL, "halo pitch is not a multiple of the sample size");
+  if ((feat & PQA_FEAT_MOTION) && !motion_fused) {
     ProfScope ps(c, 11, n, st_misc);
     if (c->motion_fixed)
       HIPCHK(c, launch_motion_fixed(st_misc, (int)c->cfg.bit_depth, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h,
@@ -528,7 +537,8 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     fa.adm_fx_top[s] = c->adm_fx[s].top; fa.adm_fx_bottom[s] = c->adm_fx[s].bottom;
     fa.adm_fx_num_shift[s] = c->adm_fx[s].num_row_shift; fa.adm_fx_den_shift[s] = c->adm_fx[s].den_row_shift;
   }
-  fa.motion_part = c->motion_part; fa.motion_tiles = c->motion_tiles_n;
+  fa.motion_part = c->motion_part;
+  fa.motion_tiles = motion_fused ? c->vif_tiles[0] : c->motion_tiles_n;   // fused: one SAD partial per VIF tile
   fa.motion_norm = (double)c->inv_scale / ((double)w * h);
   fa.motion_fx_part = c->motion_fixed ? c->motion_fx_part : nullptr;
   fa.motion_wh = (unsigned)w * (unsigned)h;
@@ -796,7 +806,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   }
   c->motion_tiles_n = motion_tiles(w, h);
   if (cfg->features & PQA_FEAT_MOTION) {
-    CREATE_TRY(dev_alloc(c, &c->motion_part, (size_t)c->motion_tiles_n * B));
+    CREATE_TRY(dev_alloc(c, &c->motion_part,
+                         (size_t)(c->motion_tiles_n > c->vif_tiles[0] ? c->motion_tiles_n : c->vif_tiles[0]) * B));
     if (c->motion_fixed) CREATE_TRY(dev_alloc(c, &c->motion_fx_part, (size_t)c->motion_tiles_n * B));
     c->last_luma_pitch = round_up((int64_t)w * c->esize, 64);
     CREATE_TRY(dev_alloc(c, &c->last_luma, (size_t)c->last_luma_pitch * h));

@@ -403,3 +403,38 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
             eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [pitch * es], [pitch * h * es])
             odd = eng.collect(0, n)[:, :8]
         assert np.array_equal(odd.view(np.uint64), valu.view(np.uint64))
+
+
+@pytest.mark.parametrize("w,h,bpc,border", [(640, 360, 8, 0), (641, 363, 8, 1), (1000, 200, 10, 1), (1920, 1080, 8, 1)])
+def test_fused_motion_experiment_matches_the_motion_kernel(oracle32, w, h, bpc, border):
+    """PQA_FUSE_MOTION=1 (opt-in; slower): motion as a sixth plane of the matrix-core VIF kernel --
+    exact integer frame difference, 5-tap band on MFMA, horizontal blur + |.| sum in the VIF tile loop.  Same values as the
+    standalone motion kernel up to summation order (1e-6 relative), inside the oracle bar, 0 for the first frame and across
+    batch seams with the one-frame halo; every other feature bit-identical to the unfused run."""
+    import os
+    from pqa2_amd import synth
+    from pqa2_amd.engine import FeatureEngine
+    n = 5
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
+
+    def run(fuse):
+        old = os.environ.get("PQA_FUSE_MOTION")
+        os.environ["PQA_FUSE_MOTION"] = fuse
+        try:
+            with FeatureEngine(w, h, bit_depth=bpc, vif_border=border, max_batch=2) as eng:   # 3 batches: halo carried twice
+                for i in range(n):
+                    eng.submit(i, refs[i], diss[i])
+                return eng.collect(0, n)
+        finally:
+            if old is None:
+                os.environ.pop("PQA_FUSE_MOTION", None)
+            else:
+                os.environ["PQA_FUSE_MOTION"] = old
+
+    plain, fused = run("0"), run("1")
+    assert np.array_equal(plain[:, :16].view(np.uint64), fused[:, :16].view(np.uint64))
+    assert fused[0, 16] == 0.0 and np.all(fused[1:, 16] > 0)
+    assert not np.array_equal(plain[:, 16], fused[:, 16]), "the switch did not change the path"
+    np.testing.assert_allclose(fused[:, 16], plain[:, 16], rtol=1e-6, atol=0)
+    exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc, vif_border101=bool(border))
+    assert np.abs(fused[:, 16] - exp[:, 16]).max() < 2e-5 + 5e-6 * exp[:, 16].max()
