@@ -13,7 +13,7 @@ mkdir -p "$OUT" "$RAW"
 export TMPDIR=/tmp
 cd /tmp
 say() { echo "$(date +%T) $*" | tee -a "$OUT/progress.log"; }
-T="timeout -k 10 150"
+T="timeout -k 10 75"
 # 96 frames = three full launches of 32 (frames per launch is then exact); short, so a profiler stall costs little
 FRAMES=96
 B="$R/bench.py --workload $WL --steps 2 --warmup 1 --frames $FRAMES --no-cpu-baseline --no-other-configs --no-e2e"

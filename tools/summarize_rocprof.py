@@ -43,7 +43,11 @@ pmc = collections.defaultdict(dict)
 for kind, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
     if not d:
         continue
-    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    found = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+    if not found:   # the pass failed or timed out: no figures from it
+        print(f"no counter_collection.csv under {d}: {kind} missing")
+        continue
+    f = found[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if "pqa::" not in r["Kernel_Name"] or r["Counter_Name"] != kind:
@@ -52,6 +56,9 @@ for kind, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
     for k, (n, v) in agg.items():
         pmc[k][kind + "_KB_per_launch"] = v / n
         pmc[k]["launches_" + kind] = n
+if any("FETCH_SIZE_KB_per_launch" not in d or "WRITE_SIZE_KB_per_launch" not in d for d in pmc.values()):
+    print("incomplete traffic passes: no pmc.json / kernel_counters.json written")
+    pmc = {}
 for k, d in pmc.items():
     fb = d.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024
     wb = d.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
