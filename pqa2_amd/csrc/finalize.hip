@@ -1,7 +1,8 @@
 // Second-stage reduction: every per-tile partial of a batch -> one 24-slot record per frame.
 // One workgroup per (frame, quantity group) walks each partial array in a FIXED order (thread-strided, then the same
-// shuffle/LDS tree), so a frame's record does not depend on batch size, launch order or GPU count:
-// 1-, 2-, 4- and 8-GPU runs are bit-identical.  Record layout: include/pqa_vmaf.h (PQA_REC_*).
+// shuffle/LDS tree), so a frame's record does not depend on how frames are split over batches, launches or ranks (by
+// construction; checked with 1, 2 and 3 ranks sharing one GPU -- a run on separate GPUs has not been possible yet).
+// Record layout: include/pqa_vmaf.h (PQA_REC_*).
 #include "kernels.h"
 #include "pqa_device.h"
 

@@ -14,7 +14,7 @@
 //   2. horizontal pass: lane <-> (row pair, 4-column segment); ds_read_b128 of input pairs, conflict-free
 //      by construction (see the lane map below); out{2p,2p+1}[o] += c[k] * in{2p,2p+1}[o+k].
 //   3. statistic on the pair, DPP wave sum, one (num, den) double partial per tile; a fixed-order second
-//      stage (finalize.hip) makes 1..8-GPU results bit-identical.
+//      stage (finalize.hip) keeps a frame's record independent of batch size and rank count.
 // HBM traffic: the two input planes once (halo re-reads hit L2) + the half-resolution planes written once.
 #include <cstring>
 #include <mutex>
