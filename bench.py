@@ -259,6 +259,7 @@ def main():
             out["other_configs"] = _other_configs(args)
         if world == 1 and args.workload == "2160p" and not args.fixed_point and not args.no_e2e:
             out["e2e"] = _e2e_leg()
+            out["bookend"] = _bookend_leg()
         out["libvmaf_side_by_side"] = "not available: no ffmpeg / libvmaf on this box (cpu_baseline.kind = port)"
         print(json.dumps(out), flush=True)
     eng.close()
@@ -309,6 +310,24 @@ def _e2e_leg():
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return out
+
+
+def _bookend_leg():
+    """The step in front of the scoring path: the luma-statistics kernel on a resident 1080p clip
+    against the HBM roofline, and bookend.detect() end to end on a Y4M file (tools/bookend_bench.py, child process)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bookend_bench.py"), "--size", "1920x1080",
+                            "--frames", "300"], capture_output=True, text=True, timeout=300)
+        d = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
+        return {"luma_stats_resident_GBps": d["resident"]["GB_per_s"], "luma_stats_hbm_frac": d["resident"]["hbm_frac"],
+                "detect_clip_frames_per_s": d["detect"]["clip_frames_per_s"],
+                "detect_numpy_clip_frames_per_s": d["detect_numpy"]["clip_frames_per_s"],
+                "same_bookends_as_numpy": d["detect_numpy"]["same_result"],
+                "what": "1920x1080, 300 frames, two white sections; resident = pqa_luma_stats_device, detect = "
+                        "pqa2_amd.bookend.detect on a Y4M file through pqa_luma_stats"}
+    except Exception as e:
+        return {"error": (str(e) or "failed")[:200]}
 
 
 def kernel_source_hash() -> str:
