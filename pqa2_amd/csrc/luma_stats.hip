@@ -33,35 +33,51 @@ __global__ __launch_bounds__(kBlock) void luma_stats_kernel(const LumaArgs a) {
   const int tid = threadIdx.x;
   constexpr int VEC = 16 / sizeof(T);
   const bool aligned = ((a.row_pitch * sizeof(T)) % 16 == 0) && ((uintptr_t)p % 16 == 0);
-  const int wv = aligned ? a.w / VEC : 0;
   unsigned long long sum = 0, sq = 0, cnt = 0;
-  for (int y = blockIdx.x; y < a.h; y += gridDim.x) {
-    const T* row = p + (int64_t)y * a.row_pitch;
-    unsigned rs = 0, rq = 0, rc = 0;  // per-row 32-bit accumulators (8-bit rows cannot overflow them)
-    for (int v = tid; v < wv; v += kBlock) {
-      const uint4 x = reinterpret_cast<const uint4*>(row)[v];
-      const unsigned xs[4] = {x.x, x.y, x.z, x.w};
+  const auto eat = [&](const uint4 x, unsigned& rs, unsigned& rq, unsigned& rc) {
+    const unsigned xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (sizeof(T) == 1) {
-          rs = __builtin_amdgcn_udot4(xs[i], 0x01010101u, rs, false);
-          rq = __builtin_amdgcn_udot4(xs[i], xs[i], rq, false);
-          rc += count_gt4(xs[i], a.threshold);
-        } else {
-          const unsigned lo = xs[i] & 0xffffu, hi = xs[i] >> 16;
-          sum += lo + hi;
-          sq += (unsigned long long)lo * lo + (unsigned long long)hi * hi;
-          rc += (lo > a.threshold ? 1u : 0u) + (hi > a.threshold ? 1u : 0u);
-        }
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (sizeof(T) == 1) {
+        rs = __builtin_amdgcn_udot4(xs[i], 0x01010101u, rs, false);
+        rq = __builtin_amdgcn_udot4(xs[i], xs[i], rq, false);
+        rc += count_gt4(xs[i], a.threshold);
+      } else {
+        const unsigned lo = xs[i] & 0xffffu, hi = xs[i] >> 16;
+        sum += lo + hi;
+        sq += (unsigned long long)lo * lo + (unsigned long long)hi * hi;
+        rc += (lo > a.threshold ? 1u : 0u) + (hi > a.threshold ? 1u : 0u);
       }
     }
-    for (int x = wv * VEC + tid; x < a.w; x += kBlock) {
-      const unsigned v = row[x];
-      sum += v;
-      sq += (unsigned long long)v * v;
-      rc += v > a.threshold ? 1u : 0u;
+  };
+  if ((uintptr_t)p % 16 == 0 && a.row_pitch == a.w && ((int64_t)a.w * a.h * (int64_t)sizeof(T)) % 16 == 0) {
+    // contiguous plane (no row padding): one flat grid-stride sweep, every lane busy whatever the row length
+    // (a 1080p row is 120 16-byte vectors: the row-by-row form below keeps 136 of 256 lanes idle there)
+    const int64_t nv = (int64_t)a.w * a.h * (int64_t)sizeof(T) / 16;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    for (int64_t v0 = (int64_t)blockIdx.x * kBlock * 8; v0 < nv; v0 += (int64_t)gridDim.x * kBlock * 8) {
+      unsigned rs = 0, rq = 0, rc = 0;   // 8 vectors of 16 bytes per lane: 32-bit partial sums cannot overflow
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t v = v0 + (int64_t)u * kBlock + tid;
+        if (v < nv) eat(q[v], rs, rq, rc);
+      }
+      sum += rs; sq += rq; cnt += rc;
     }
-    sum += rs; sq += rq; cnt += rc;
+  } else {
+    const int wv = aligned ? a.w / VEC : 0;
+    for (int y = blockIdx.x; y < a.h; y += gridDim.x) {
+      const T* row = p + (int64_t)y * a.row_pitch;
+      unsigned rs = 0, rq = 0, rc = 0;  // per-row 32-bit accumulators (8-bit rows cannot overflow them)
+      for (int v = tid; v < wv; v += kBlock) eat(reinterpret_cast<const uint4*>(row)[v], rs, rq, rc);
+      for (int x = wv * VEC + tid; x < a.w; x += kBlock) {
+        const unsigned v = row[x];
+        sum += v;
+        sq += (unsigned long long)v * v;
+        rc += v > a.threshold ? 1u : 0u;
+      }
+      sum += rs; sq += rq; cnt += rc;
+    }
   }
   unsigned long long v[3] = {sum, sq, cnt};
 #pragma unroll

@@ -43,6 +43,7 @@ struct ProfEv {
 };
 
 constexpr int kBatchEvents = 64;  // ring of per-batch completion events
+constexpr int kLumaOutFrames = 2048;  // luma statistics kept on the device between host copies
 enum : uint8_t { kSlotEmpty = 0, kSlotSubmitted = 1, kSlotCollected = 2 };
 
 // pqa_submit packs the caller's planes into pinned staging.  One core's memcpy (~10 GB/s) is far below PCIe, so the
@@ -826,7 +827,7 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     }
   }
   CREATE_TRY(dev_alloc(c, &c->luma_part, (size_t)kLumaBlocks * 3 * B));
-  CREATE_TRY(dev_alloc(c, &c->luma_out, (size_t)3 * B));
+  CREATE_TRY(dev_alloc(c, &c->luma_out, (size_t)3 * (B > kLumaOutFrames ? B : kLumaOutFrames)));
   if (c->adm_fixed) {
     CREATE_TRY(dev_alloc(c, &c->adm_fx_acc, (size_t)c->capacity * 24));
     CREATE_HIP(hipMemsetAsync(c->adm_fx_acc, 0, (size_t)c->capacity * 24 * sizeof(long long), c->stream));
@@ -1104,14 +1105,21 @@ int pqa_luma_stats_device(pqa_ctx* c, const void* luma, int64_t row_pitch, int64
   if (row_pitch % c->esize || frame_pitch % c->esize) return fail(c, PQA_EINVAL, "pitch is not a multiple of the sample size");
   if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
   HIPCHK(c, hipSetDevice(c->device));
+  // launches of up to B frames each write their results side by side into luma_out (kLumaOutFrames frames); the host
+  // copy and the sync happen once per kLumaOutFrames frames, not once per launch
   for (int done = 0; done < n_frames;) {
-    const int n = n_frames - done < c->B ? n_frames - done : c->B;
-    const PlaneRun run{(const uint8_t*)luma + (int64_t)done * frame_pitch, row_pitch / c->esize, frame_pitch / c->esize};
-    HIPCHK(c, launch_luma_stats(c->stream, c->elem, run, n, c->pw[0], c->ph[0], threshold, c->luma_part, c->luma_out));
-    HIPCHK(c, hipMemcpyAsync(out + (size_t)done * 3, c->luma_out, (size_t)n * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+    const int group = n_frames - done < kLumaOutFrames ? n_frames - done : kLumaOutFrames;
+    for (int g0 = 0; g0 < group;) {
+      const int n = group - g0 < c->B ? group - g0 : c->B;
+      const PlaneRun run{(const uint8_t*)luma + (int64_t)(done + g0) * frame_pitch, row_pitch / c->esize, frame_pitch / c->esize};
+      HIPCHK(c, launch_luma_stats(c->stream, c->elem, run, n, c->pw[0], c->ph[0], threshold, c->luma_part,
+                                  c->luma_out + (size_t)g0 * 3));
+      g0 += n;
+    }
+    HIPCHK(c, hipMemcpyAsync(out + (size_t)done * 3, c->luma_out, (size_t)group * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    done += n;
+    done += group;
   }
   return PQA_OK;
 }
