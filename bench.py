@@ -304,7 +304,8 @@ def _e2e_leg():
             best = max(lines, key=lambda x: x["fps_end_to_end"])
             out[size] = {"fps_end_to_end": best["fps_end_to_end"], "frames": frames, "seconds": best["seconds"],
                          "what": "2 Y4M files (page cache) -> analyze_videos -> JSON + psnr.txt + ssim.txt, all planes, "
-                                 "vmaf_v0.6.1; context creation and file writing included"}
+                                 "vmaf_v0.6.1; context creation and file writing included; the better of two passes in one "
+                                 "process (the second finds the pinned staging buffers of the first parked in the library)"}
         except Exception as e:
             out[size] = {"error": (str(e) or "failed")[:200]}
         finally:

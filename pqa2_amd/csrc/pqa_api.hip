@@ -127,6 +127,34 @@ class PackPool {
   bool stop_ = false;
 };
 
+// Staging buffers of the host path outlive their context: pinning 2 x 200 MB (2160p 4:2:0, 8 frames) and releasing it again
+// costs ~55 ms per context -- more than scoring a 48-frame 2160p clip -- and the reference's caller makes a fresh analyzer
+// per run (app/ui/tabs/analysis_tab.py:588).  One set per process is kept for the next context of the same device and
+// size (PQA_STAGING_CACHE=0: off; anything else it holds is released when a differently sized set is parked).
+struct StagingSet {
+  int device = -1;
+  size_t bytes = 0;
+  uint8_t* pinned[2] = {nullptr, nullptr};
+  uint8_t* dev[2] = {nullptr, nullptr};
+};
+std::mutex g_staging_mu;
+StagingSet g_staging;   // guarded by g_staging_mu; empty when bytes == 0
+
+bool staging_cache_enabled() {
+  const char* e = getenv("PQA_STAGING_CACHE");
+  return !(e && e[0] == '0');
+}
+
+void staging_release(StagingSet& s) {   // caller holds the lock or owns s; the right device must be current
+  for (int i = 0; i < 2; ++i) {
+    if (s.pinned[i]) hipHostFree(s.pinned[i]);
+    if (s.dev[i]) hipFree(s.dev[i]);
+    s.pinned[i] = s.dev[i] = nullptr;
+  }
+  s.bytes = 0;
+  s.device = -1;
+}
+
 }  // namespace
 
 struct pqa_ctx {
@@ -607,10 +635,27 @@ int ensure_staging(pqa_ctx* c) {
       off += round_up(c->slot_row_pitch[p] * c->ph[p], 256);
     }
   c->slot_bytes = off;
+  const size_t half_bytes = c->slot_bytes * c->HB;
+  bool reused = false;
+  if (staging_cache_enabled()) {
+    std::lock_guard<std::mutex> g(g_staging_mu);
+    if (g_staging.bytes == half_bytes && g_staging.device == c->device) {
+      for (int i = 0; i < 2; ++i) {
+        c->half[i].pinned = g_staging.pinned[i];
+        c->half[i].dev = g_staging.dev[i];
+        g_staging.pinned[i] = g_staging.dev[i] = nullptr;
+      }
+      g_staging.bytes = 0;
+      g_staging.device = -1;
+      reused = true;
+    }
+  }
   for (int i = 0; i < 2; ++i) {
     Half& H = c->half[i];
-    HIPCHK(c, hipHostMalloc((void**)&H.pinned, c->slot_bytes * c->HB, hipHostMallocDefault));
-    HIPCHK(c, hipMalloc((void**)&H.dev, c->slot_bytes * c->HB));
+    if (!reused) {
+      HIPCHK(c, hipHostMalloc((void**)&H.pinned, half_bytes, hipHostMallocDefault));
+      HIPCHK(c, hipMalloc((void**)&H.dev, half_bytes));
+    }
     HIPCHK(c, hipEventCreateWithFlags(&H.copied, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&H.computed, hipEventDisableTiming));
   }
@@ -849,10 +894,30 @@ void pqa_destroy(pqa_ctx* c) {
   for (int i = 0; i < 2; ++i) if (c->aux[i]) hipStreamSynchronize(c->aux[i]);
   prof_drain(c);
   for (void* p : c->allocs) hipFree(p);
+  {  // park the staging buffers for the next context (everything using them has been synchronised above)
+    StagingSet mine;
+    mine.device = c->device;
+    mine.bytes = c->slot_bytes * (size_t)c->HB;
+    bool complete = c->staging_ready;
+    for (int i = 0; i < 2; ++i) {
+      mine.pinned[i] = c->half[i].pinned;
+      mine.dev[i] = c->half[i].dev;
+      complete = complete && mine.pinned[i] && mine.dev[i];
+    }
+    if (complete && staging_cache_enabled()) {
+      std::lock_guard<std::mutex> g(g_staging_mu);
+      if (g_staging.bytes) {           // one set per process: the older one goes
+        if (g_staging.device != c->device) hipSetDevice(g_staging.device);
+        staging_release(g_staging);
+        hipSetDevice(c->device);
+      }
+      g_staging = mine;
+    } else {
+      staging_release(mine);
+    }
+  }
   for (int i = 0; i < 2; ++i) {
     Half& H = c->half[i];
-    if (H.pinned) hipHostFree(H.pinned);
-    if (H.dev) hipFree(H.dev);
     if (H.copied) hipEventDestroy(H.copied);
     if (H.computed) hipEventDestroy(H.computed);
   }
