@@ -23,7 +23,7 @@ CASES = [("c64x48_8", 64, 48, 8, 3), ("c176x144_8", 176, 144, 8, 3), ("c321x241_
          ("c200x120_10", 200, 120, 10, 2), ("c352x288_8", 352, 288, 8, 3)]
 # clips also committed as .y4m under clips/: the inputs of tools/compare_libvmaf_log.py (run ffmpeg+libvmaf on them
 # wherever one exists, diff its JSON log against every restatement here)
-Y4M_CASES = ("c64x48_8", "c352x288_8")
+Y4M_CASES = ("c64x48_8", "c352x288_8", "c200x120_10")
 
 
 def main():

@@ -42,7 +42,7 @@ def _run(args):
 def test_committed_clips_are_the_golden_inputs():
     from pqa2_amd.yuvio import open_video
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_features.json")))["cases"]
-    for name in ("c64x48_8", "c352x288_8"):
+    for name in ("c64x48_8", "c352x288_8", "c200x120_10"):
         rd, dd = open_video(os.path.join(CLIPS, f"{name}_ref.y4m")), open_video(os.path.join(CLIPS, f"{name}_dist.y4m"))
         assert len(rd) == len(dd) == g[name]["n"] and (rd.info.width, rd.info.height) == (g[name]["w"], g[name]["h"])
         sha = hashlib.sha256()
@@ -69,3 +69,34 @@ def test_tool_reports_match_and_mismatch(tmp_path):
     flog = _log_from_restatement(tmp_path, "c64x48_8", 64, 48, integer=False)
     r = _run([flog, ref, dis])
     assert r.returncode == 0 and "vif_tools.c border" in r.stdout and "fixed-point restatement" not in r.stdout
+
+
+def test_ffmpeg_stats_tool_on_its_own_output(tmp_path):
+    """tools/compare_ffmpeg_stats.py (row a5): fed stats files written by this repository's own writers it must report a
+    match; a changed digit in a PSNR line and a moved SSIM field must both be flagged."""
+    from oracle.oracle import Oracle
+    from pqa2_amd import report
+    from pqa2_amd.yuvio import open_video
+    ref, dis = os.path.join(CLIPS, "c200x120_10_ref.y4m"), os.path.join(CLIPS, "c200x120_10_dist.y4m")
+    rd, dd = open_video(ref), open_video(dis)
+    info, n = rd.info, len(rd)
+    assert info.bit_depth == 10
+    sizes = [(info.width, info.height), (info.chroma_w, info.chroma_h), (info.chroma_w, info.chroma_h)]
+    orc = Oracle("f32")
+    sse = np.array([[orc.sse_plane(dd.frame(i)[p], rd.frame(i)[p], 10) for p in range(3)] for i in range(n)], np.uint64)
+    ssim = np.array([[orc.ssim_plane(dd.frame(i)[p], rd.frame(i)[p], 10) for p in range(3)] for i in range(n)])
+    pp, sp = str(tmp_path / "psnr.txt"), str(tmp_path / "ssim.txt")
+    open(pp, "w").write("\n".join(report.psnr_stats_lines(sse, sizes, 10)) + "\n")
+    open(sp, "w").write("\n".join(report.ssim_stats_lines(ssim, sizes)) + "\n")
+    tool = os.path.join(ROOT, "tools", "compare_ffmpeg_stats.py")
+    run = lambda args: subprocess.run([sys.executable, tool] + args, capture_output=True, text=True, timeout=300,
+                                      env=dict(os.environ, PYTHONPATH=ROOT))
+    r = run(["--psnr", pp, "--ssim", sp, ref, dis])
+    assert r.returncode == 0 and "IDENTICAL text" in r.stdout and "row a5 is pinned" in r.stdout, r.stdout + r.stderr
+    lines = open(pp).read().split("\n")
+    lines[0] = lines[0].replace("mse_avg:", "mse_avg:1", 1)
+    open(pp, "w").write("\n".join(lines))
+    ssim[1, 0] += 1e-4
+    open(sp, "w").write("\n".join(report.ssim_stats_lines(ssim, sizes)) + "\n")
+    r = run(["--psnr", pp, "--ssim", sp, ref, dis])
+    assert r.returncode == 1 and r.stdout.count("MISMATCH") >= 3
