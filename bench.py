@@ -188,7 +188,10 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not args.fixed_point else f"f32 + fixed-point extractors (mask {args.fixed_point})", "data": "synthetic",
+            "dtype": ("f32" if not args.fixed_point else f"f32 + fixed-point extractors (mask {args.fixed_point})"), "data": "synthetic",
+            "dtype_note": "every filter and statistic accumulates in f32; VIF scale 0's vertical pass multiplies exact integer digit "
+                          "planes by exact f16 tap pieces on the matrix cores (products exact in f32, f32 accumulators): no "
+                          "reduced-precision arithmetic anywhere",
             "config": {"workload": f"{args.workload} {w}x{h} {bpc}-bit, {model_name}, {F} frames/GPU"
                                    f"{' + PSNR/SSIM all planes' if side else ''}"
                                    f"{f' [--fixed-point {args.fixed_point}: libvmaf integer arithmetic]' if args.fixed_point else ''}",
