@@ -440,3 +440,26 @@ def test_fused_motion_experiment_matches_the_motion_kernel(oracle32, w, h, bpc, 
     np.testing.assert_allclose(fused[:, 16], plain[:, 16], rtol=1e-6, atol=0)
     exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc, vif_border101=bool(border))
     assert np.abs(fused[:, 16] - exp[:, 16]).max() < 2e-5 + 5e-6 * exp[:, 16].max()
+
+
+def test_worst_known_hd_flip_case_stays_bounded():
+    """The one HD-size pair any fuzz run has produced above the 0.01 VMAF target: 1039 x 913, gain
+    limit 1.5, a single ADM scale-3 coefficient's angle test.  Kept as data (tests/flip_cases); the kernels must stay
+    within 0.012 of the f64 oracle values stored with it, and every feature but ADM scale 3's numerator within 5e-6."""
+    import os
+    from pqa2_amd.engine import FeatureEngine
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "flip_cases", "r02_1039x913_k4.npz"))
+    w, h, bpc, kind, gain, border = d["tag"]
+    w, h = int(w), int(h)
+    with FeatureEngine(w, h, vif_enhn_gain_limit=float(gain), adm_enhn_gain_limit=float(gain), vif_border=int(border)) as eng:
+        for i in range(2):
+            eng.submit(i, [d["ref"][i]], [d["dis"][i]])
+        got = eng.collect(0, 2)[:, :17]
+    rel = np.abs(got[:, :16] - d["exp"][:, :16]) / np.abs(d["exp"][:, :16])
+    others = np.delete(rel, 11, axis=1)
+    assert others.max() < 5e-6, others.max()
+    mdl = M.load_model("vmaf_v0.6.1")
+    def vm(r):
+        full = np.zeros((2, 24)); full[:, :17] = r
+        return M.score_frames(mdl, M.metrics_from_records(full, w, h))["vmaf"]
+    assert np.abs(vm(got) - vm(d["exp"])).max() < 0.012
