@@ -192,28 +192,27 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
         ld[(unsigned)cyB * (unsigned)a.ll_row_pitch_d + (unsigned)cx] = da.y;
       }
     }
-    // decouple: libvmaf computes k = clamp(t / (o + eps), 0, 1) and r = k * o.  In exact arithmetic that is
-    //   r = t  when t and o have the same sign and |t| <= |o|   (0 <= t/o <= 1)
-    //   r = o  when they have the same sign and |t| >  |o|     (t/o > 1 -> k = 1)
-    //   r = 0  when the signs differ or o == 0                 (t/o < 0 -> k = 0; o = 0: k * 0)
-    // i.e. r = median(0, t, o): ONE v_med3_f32 per coefficient and orientation, no division (the round-1 form was
-    // v_rcp_f32 + a Newton step + clamp + multiply: 7 instructions and a transcendental).  libvmaf's f32 r = fl(fl(t/o) * o)
-    // sits within one ulp of t in the first case; the median returns t itself, which is what the f64 oracle gets too.
-    const f2 z2 = splat(0.0f);
-    f2 rh = med3_2(z2, th, oh), rv = med3_2(z2, tv, ov), rd = med3_2(z2, td, od);
+    // decouple + enhancement-gain limit.  libvmaf computes k = clamp(t / (o + eps), 0, 1), r = k * o and, where the angle
+    // between (o_h, o_v) and (t_h, t_v) is below one degree, r = min(r * limit, t) for r > 0 / max(r * limit, t) for r < 0.
+    // In exact arithmetic k * o is
+    //   t  when t and o have the same sign and |t| <= |o|   (0 <= t/o <= 1)
+    //   o  when they have the same sign and |t| >  |o|     (t/o > 1 -> k = 1)
+    //   0  when the signs differ or o == 0                 (t/o < 0 -> k = 0; o = 0: k * 0)
+    // i.e. the median of {0, t, o}; and the limited value, case by case (limit >= 1), is the median of {0, t, limit * o}:
+    //   same sign, |t| <= limit |o|  ->  t      (r was t, or r was o and min(o * limit, t) = t)
+    //   same sign, |t| >  limit |o|  ->  limit o
+    //   signs differ / o == 0        ->  0      ("r == 0 stays")
+    // So r = med3(0, t, o * m) with m = limit under the angle test and 1 otherwise: one select per coefficient, one
+    // multiply and ONE v_med3_f32 per orientation, no division.  (Round 1: v_rcp_f32 + Newton step + clamp + multiply for k,
+    // then a second median and a select per orientation.)  libvmaf's f32 r = fl(fl(t/o) * o) sits within one ulp of t in
+    // the first case; the median returns t itself, which is what the f64 oracle gets too.
     const f2 ot_dp = __builtin_elementwise_fma(ov, tv, oh * th);
     const f2 o_mag_sq = __builtin_elementwise_fma(ov, ov, oh * oh), t_mag_sq = __builtin_elementwise_fma(tv, tv, th * th);
     const f2 lhs = ot_dp * ot_dp, rhs = splat(cos_1deg_sq) * o_mag_sq * t_mag_sq;
     const bool angA = (ot_dp.x >= 0.0f) && (lhs.x >= rhs.x), angB = (ot_dp.y >= 0.0f) && (lhs.y >= rhs.y);
-    // enhancement-gain limit under the angle test: r > 0 -> min(r*limit, t); r < 0 -> max(r*limit, t);
-    // r == 0 stays.  Because r = clamp(t/o, 0, 1) * o lies between 0 and t and limit >= 1, all three cases
-    // are the median of {r, r*limit, t}: one v_med3_f32 (differs from the branchy form only when k*o
-    // rounds 1 ulp past t).
-    const f2 gl = splat(a.gain_limit);
-    const f2 mh = med3_2(rh, rh * gl, th), mv = med3_2(rv, rv * gl, tv), md = med3_2(rd, rd * gl, td);
-    rh = f2{angA ? mh.x : rh.x, angB ? mh.y : rh.y};
-    rv = f2{angA ? mv.x : rv.x, angB ? mv.y : rv.y};
-    rd = f2{angA ? md.x : rd.x, angB ? md.y : rd.y};
+    const f2 z2 = splat(0.0f);
+    const f2 m2 = f2{angA ? a.gain_limit : 1.0f, angB ? a.gain_limit : 1.0f};
+    const f2 rh = med3_2(z2, th, oh * m2), rv = med3_2(z2, tv, ov * m2), rd = med3_2(z2, td, od * m2);
     // CSF of the additive image; adm_cm_s sums the 3x3 boxes per orientation and then over
     // orientations -- summing over orientations first is the same value up to float rounding
     // (|rf_hv a_h| + |rf_hv a_v| + |rf_d a_d|) / 30 with the constants folded: k_hv (|a_h| + |a_v|) + k_d |a_d|
