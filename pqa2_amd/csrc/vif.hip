@@ -82,7 +82,6 @@ struct VifStatArgs {
   // Units are tiles for vif_stat_kernel and vertically adjacent tile PAIRS (2p, 2p+1) for vif_s0_mfma_kernel.
   int tx_lo, tx_hi, ty_lo, ty_hi, grid_rows;
   const uint4* atab;   // MFMA kernel: per-lane tap-matrix fragments (kAtabFrags x 64 lanes x 8 f16)
-  float lo_bias;       // MFMA kernel: -1024 * (sum of the two low-plane tap pieces over the 17-tap band)
   // MFMA kernel with fused motion (MOTION variants): the reference luma of the previous frame is the frame before in
   // the run, or mprev0 for the run's first frame (null: that frame's motion is 0); one SAD partial per tile
   const void* mprev0;
@@ -189,7 +188,7 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
     const bool vrow[2] = {FULL || gyA < a.h, FULL || gyA + 1 < a.h};
     f2 num2 = f2{0.0f, 0.0f}, den2 = f2{0.0f, 0.0f};
     // the log terms of the sigma1_sq >= sigma_nsq branch are summed as the log of a product: per row of
-    // the pair the four columns' arguments (each in [2, 2^15]) are multiplied first, so the thread takes
+    // the pair the four columns' arguments (each in [2, 2^16]) are multiplied first, so the thread takes
     // 6 v_log_f32 instead of 16 and needs no reciprocal for num's ratio (log a/b = log a - log b)
     f2 pn = f2{1.0f, 1.0f}, qn = f2{1.0f, 1.0f}, pd = f2{1.0f, 1.0f};
 #pragma unroll
@@ -198,13 +197,24 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
       // the two rows of the pair go through the statistic together: every add / mul / fma is packed,
       // only max / min / select / rcp / log are per element
       const f2 mu1 = out[0][o], mu2 = out[1][o];
-      f2 s1 = out[2][o] - mu1 * mu1, s2 = out[3][o] - mu2 * mu2;
+      const f2 s1 = out[2][o] - mu1 * mu1;
+      f2 s2 = out[3][o] - mu2 * mu2;
       const f2 s12 = out[4][o] - mu1 * mu2;
-      s1 = f2{fmaxf(s1.x, 0.0f), fmaxf(s1.y, 0.0f)};
       s2 = f2{fmaxf(s2.x, 0.0f), fmaxf(s2.y, 0.0f)};
+      // validity and the branch choice: out-of-image positions of edge tiles hold finite values (mirrored real
+      // pixels); they and the positions of the low branch contribute a factor 1 to the log products and a weight 0 / 1
+      // to the low sums.  ONE select does it for all three products: with sigma1_sq replaced by 0 the arguments
+      // become narg = svn (cancels against qn's svn) and darg = 1.  (A select costs the VALU as much as a packed FMA.)
+      // libvmaf's MAX(sigma1_sq, 0) needs no instruction either: the log branch has sigma1_sq >= 2, everything else
+      // continues with 0.
+      const bool vx = vcol && vrow[0], vy = vcol && vrow[1];
+      const bool hx = vx && !(s1.x < sigma_nsq), hy = vy && !(s1.y < sigma_nsq);
+      const bool lx = vx && (s1.x < sigma_nsq), ly = vy && (s1.y < sigma_nsq);
+      const f2 s1h = f2{hx ? s1.x : 0.0f, hy ? s1.y : 0.0f};
       // g = sigma12 / (sigma1_sq + eps): v_rcp_f32 plus one Newton correction -- exact 1.0 when the two
-      // are equal (identical frames), 2 FMAs instead of a full IEEE division
-      const f2 gden = s1 + f2{eps, eps};
+      // are equal (identical frames), 2 FMAs instead of a full IEEE division.  (Off the log branch g is sigma12 / eps:
+      // large but finite, clamped below, and multiplied by s1h = 0.)
+      const f2 gden = s1h + f2{eps, eps};
       const f2 grcp = f2{fast_rcp(gden.x), fast_rcp(gden.y)};
       f2 g = s12 * grcp;
       g = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, gden, s12), grcp, g);
@@ -222,17 +232,12 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
       g = f2{__builtin_amdgcn_fmed3f(g.x, 0.0f, a.gain_limit), __builtin_amdgcn_fmed3f(g.y, 0.0f, a.gain_limit)};
       const f2 svn = sv + f2{sigma_nsq, sigma_nsq};
       // num_val = log2(1 + g^2 sigma1_sq / (sv_sq + sigma_nsq)) = log2(narg) - log2(svn)
-      const f2 narg = __builtin_elementwise_fma(g * g, s1, svn);
-      const f2 darg = __builtin_elementwise_fma(s1, f2{1.0f / sigma_nsq, 1.0f / sigma_nsq}, f2{1.0f, 1.0f});
+      const f2 narg = __builtin_elementwise_fma(g * g, s1h, svn);
+      const f2 darg = __builtin_elementwise_fma(s1h, f2{1.0f / sigma_nsq, 1.0f / sigma_nsq}, f2{1.0f, 1.0f});
       const f2 low = __builtin_elementwise_fma(s2, f2{-sigma_max_inv, -sigma_max_inv}, f2{1.0f, 1.0f});
-      // validity and the branch choice as selects: out-of-image positions of edge tiles hold finite values
-      // (mirrored real pixels), they contribute a factor 1 and a weight 0
-      const bool vx = vcol && vrow[0], vy = vcol && vrow[1];
-      const bool hx = vx && !(s1.x < sigma_nsq), hy = vy && !(s1.y < sigma_nsq);
-      const bool lx = vx && (s1.x < sigma_nsq), ly = vy && (s1.y < sigma_nsq);
-      pn *= f2{hx ? narg.x : 1.0f, hy ? narg.y : 1.0f};
-      qn *= f2{hx ? svn.x : 1.0f, hy ? svn.y : 1.0f};
-      pd *= f2{hx ? darg.x : 1.0f, hy ? darg.y : 1.0f};
+      pn *= narg;
+      qn *= svn;
+      pd *= darg;
       const f2 wl = f2{lx ? 1.0f : 0.0f, ly ? 1.0f : 0.0f};
       num2 = __builtin_elementwise_fma(wl, low, num2);
       den2 += wl;
@@ -429,9 +434,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef short s2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-// fragments in the table: 0-2: c*2^19 pieces (means, high digits)  3-4: c*2^11 pieces (8-bit low digits, base 256)
+// fragments in the table: 0-2: c*2^19 pieces (high digits)  3-4, 12: c*2^11 pieces (means; 3-4 also the 8-bit low digits)
 // 5-7: c'*2^18 pieces (decimation)  8-9: c*2^9 pieces (10-bit low digits, base 1024)  10-11: motion taps * 2^17, two pieces
-constexpr int kAtabFrags = 12;
+constexpr int kAtabFrags = 13;
 constexpr float kMfmaMotionScale = 1.0f / 131072.0f;   // 2^-17
 
 static void motion_taps(float f[5]) {  // FILTER_5_s of libvmaf's motion: 5 taps, sigma 1.0 (same table as motion.hip)
@@ -439,26 +444,31 @@ static void motion_taps(float f[5]) {  // FILTER_5_s of libvmaf's motion: 5 taps
   for (int k = 0; k < 5; ++k) { v[k] = exp(-0.5 * (k - 2) * (k - 2)); sum += v[k]; }
   for (int k = 0; k < 5; ++k) f[k] = (float)(v[k] / sum);
 }
-constexpr float kMfmaSqScale = 1.0f / 2048.0f;       // 2^-11: squares / cross term after the vertical pass
-constexpr float kMfmaMuScale = 1.0f / 256.0f;        // 2^-19 / 2^-11: the means carry 2^8 more
-constexpr float kMfmaDecScale = 1.0f / 262144.0f;    // 2^-18: decimation planes
 
+// an 8-byte LDS store the compiler may not fuse with its neighbour into a 16-byte one (volatile): the two halves come
+// from different accumulators, and fusing them means four register copies per store
+__device__ __forceinline__ void lds_store_f2(f2* p, f2 v) {
+  typedef __attribute__((address_space(3))) volatile f2 lds_f2;
+  *(lds_f2*)p = v;
+}
+__device__ __forceinline__ void lds_store_f32(float* p, float v) {
+  typedef __attribute__((address_space(3))) volatile float lds_f32;
+  *(lds_f32*)p = v;
+}
 // v_bfi_b32: bits of `a` where the mask is set, bits of `b` elsewhere
 __device__ __forceinline__ unsigned bfi32(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
 __device__ __forceinline__ h8 frag_from(unsigned a, unsigned b, unsigned c, unsigned d) {
   return __builtin_bit_cast(h8, u4v{a, b, c, d});
 }
-// two u8 (low bytes of the 16-bit halves of x) + 0x6400 -> two f16 (1024 + v): exact for v < 1024; then - bias
-__device__ __forceinline__ unsigned f16_pair_from_bytes(unsigned x, float bias) {
-  const h2 v = __builtin_bit_cast(h2, x | 0x64006400u) - h2{(_Float16)bias, (_Float16)bias};
-  return __builtin_bit_cast(unsigned, v);
-}
-// byte `which` (0 low, 1 high) of both 16-bit halves of x, each with 0x64 on top -> two f16 (1024 + byte), - bias
-__device__ __forceinline__ unsigned f16_pair_from_byte_of_halves(unsigned x, int which, float bias) {
-  const unsigned sel = which ? 0x04030401u : 0x04020400u;  // {0x64, byte, 0x64, byte}: source 0 = 0x64646464, source 1 = x
-  const unsigned p = __builtin_amdgcn_perm(0x64646464u, x, sel);
-  const h2 v = __builtin_bit_cast(h2, p) - h2{(_Float16)bias, (_Float16)bias};
-  return __builtin_bit_cast(unsigned, v);
+// Digits and samples go into the B operand as f16 bit patterns 0x0000 .. 0x07ff, which the f16 format reads as
+// k * 2^-24 for every k < 2048 (denormals and the first normal binade share one ulp): an integer in the low bits of a
+// 16-bit lane IS its own f16 encoding, no conversion instruction.  gfx950 keeps f16 denormals in v_pk_add_f16 and
+// in the MFMA operands (tools/ubench/f16_denorm.hip, profiles/r02j_ubench_f16_denorm.txt); the tests that compare this
+// kernel with the VALU kernel on extreme samples would catch a flush.
+// two integers k (one per 16-bit half, k < 2048) -> two f16 (k - off) * 2^-24, exact; `off_bits` = off as f16 bits | 0x8000
+__device__ __forceinline__ unsigned f16_tiny_minus(unsigned x, unsigned short off_bits) {
+  const h2 o = __builtin_bit_cast(h2, (unsigned)off_bits | ((unsigned)off_bits << 16));
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, x) + o);
 }
 
 // T = uint8_t: 8-bit samples as described above.  T = uint16_t: 10-bit samples (libvmaf: x = v / 4 - 128 = (v - 512) / 4):
@@ -502,12 +512,16 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
   const unsigned pitch_r = (unsigned)a.row_pitch_r * ES, pitch_d = (unsigned)a.row_pitch_d * ES;  // bytes
   const auto rsrc_r = make_rsrc(ref, (unsigned)a.h * pitch_r);
   const auto rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d);
-  constexpr int FRAG_LO0 = 3;   // first of the two low-digit-plane fragments (c * 2^11 pieces at 8 bit, c * 2^9 at 10 bit)
 
   // tap-matrix fragments of this lane (A operand: row = lane & 15, K group = lane >> 4)
-  h8 A[8];   // slots 3, 4 hold the low-digit pieces of this sample type
+  // slots 0-2: c * 2^19 (high digits)   3-4: low-digit pieces of this sample type   5-7: c' * 2^18 (decimation)
+  // 8..: the pieces of c * 2^11 the mean planes use that slots 3-4 do not already hold
+  constexpr int NA = W16 ? 11 : 9;
+  constexpr int kSlotFrag[11] = {0, 1, 2, W16 ? 8 : 3, W16 ? 9 : 4, 5, 6, 7, W16 ? 3 : 12, 4, 12};
+  constexpr int MU0 = W16 ? 8 : 3, MU1 = W16 ? 9 : 4, MU2 = W16 ? 10 : 8;
+  h8 A[NA];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) A[f] = __builtin_bit_cast(h8, a.atab[((W16 && (f == 3 || f == 4)) ? f + 5 : f) * 64 + lane]);
+  for (int f = 0; f < NA; ++f) A[f] = __builtin_bit_cast(h8, a.atab[kSlotFrag[f] * 64 + lane]);
   h8 Am[2];  // motion band pieces
   if (MOTION) {
     Am[0] = __builtin_bit_cast(h8, a.atab[10 * 64 + lane]);
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
   // motion mirrors like the float extractors (fold 2n - 1) whatever border VIF uses
   const bool same_fold = a.fold_w == 2 * a.w - 1 && a.fold_h == 2 * a.h - 1;
 
-  f4 park[2][5];   // lower tile's rows {2g, 2g+1} x columns {2n, 2n+1} per pass and signal
+  f2 park[2][5][2];   // lower tile's rows {2g, 2g+1} of columns 2n, 2n+1 per pass and signal
   f4 park_d[2];    // lower tile's decimation row g: {ref, dis} x 2 columns
   f4 park_m[2];    // lower tile's motion rows
 #pragma unroll
@@ -613,11 +627,8 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
       }
     }
     f4 D[5][2], Dd[2][2], Dm[2];
-    // Accumulators start in the FIRST product of each chain (srcC = a constant) instead of being cleared one by one.
-    // The low digit planes go in as 1024 + digit (no subtraction in the operand): every output row sees the full
-    // 17-tap band, so that adds the constant 1024 * sum(band) -- taken off by starting those chains at lo_bias
-    // (exact; smaller than the signal itself).
-    const f4 zero4 = f4{0.0f, 0.0f, 0.0f, 0.0f}, bias4 = f4{a.lo_bias, a.lo_bias, a.lo_bias, a.lo_bias};
+    // Accumulators start in the FIRST product of each chain (srcC = 0) instead of being cleared one by one.
+    const f4 zero4 = f4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       // 16-bit lanes {row 2v, row 2v+1} of this N-block's column (K order of the B operand: element j = row 8g + j)
@@ -635,17 +646,18 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
       unsigned t[4];
 #define PQA_MMA(Dacc, frag) Dacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[frag], B, Dacc, 0, 0, 0)
 #define PQA_MMA0(Dacc, frag, C0) Dacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[frag], B, C0, 0, 0, 0)
-      {  // means: r' and d' (sample - mid-grey, exact in f16), plus the next scale's input from the same operands
+      constexpr unsigned short MID_TINY = W16 ? 0x8200 : 0x8080;   // -MID * 2^-24 as f16 bits
+      {  // means: r' and d' (sample - mid-grey) * 2^-24, plus the next scale's input from the same operands
 #pragma unroll
-        for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(ru[v], 1024.0f + MID);
+        for (int v = 0; v < 4; ++v) t[v] = f16_tiny_minus(ru[v], MID_TINY);
         const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-        PQA_MMA0(D[0][b], 0, zero4); PQA_MMA0(Dd[0][b], 5, zero4); PQA_MMA(D[0][b], 1); PQA_MMA(Dd[0][b], 6); PQA_MMA(D[0][b], 2); PQA_MMA(Dd[0][b], 7);
+        PQA_MMA0(D[0][b], MU0, zero4); PQA_MMA0(Dd[0][b], 5, zero4); PQA_MMA(D[0][b], MU1); PQA_MMA(Dd[0][b], 6); PQA_MMA(D[0][b], MU2); PQA_MMA(Dd[0][b], 7);
       }
       {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) t[v] = f16_pair_from_bytes(du[v], 1024.0f + MID);
+        for (int v = 0; v < 4; ++v) t[v] = f16_tiny_minus(du[v], MID_TINY);
         const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-        PQA_MMA0(D[1][b], 0, zero4); PQA_MMA0(Dd[1][b], 5, zero4); PQA_MMA(D[1][b], 1); PQA_MMA(Dd[1][b], 6); PQA_MMA(D[1][b], 2); PQA_MMA(Dd[1][b], 7);
+        PQA_MMA0(D[1][b], MU0, zero4); PQA_MMA0(Dd[1][b], 5, zero4); PQA_MMA(D[1][b], MU1); PQA_MMA(Dd[1][b], 6); PQA_MMA(D[1][b], MU2); PQA_MMA(Dd[1][b], 7);
       }
       if (MOTION) {  // frame difference of the reference (exact integers, |.| <= 255 / 1023), 5-tap band, two tap pieces
         if (have_prev) {
@@ -662,7 +674,7 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
           Dm[b] = zero4;   // first frame of a clip: motion is 0
         }
       }
-      // squares and cross term: integer products (exact), digits straight out of their bits
+      // squares and cross term: integer products (exact); their digits are f16 operands as they are (k * 2^-24)
 #pragma unroll
       for (int s = 2; s < 5; ++s) {
         if (!W16) {
@@ -671,20 +683,21 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
           for (int v = 0; v < 4; ++v) {
             const s2v x = __builtin_bit_cast(s2v, s == 3 ? d16[v] : r16[v]);
             const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
-            q[v] = __builtin_bit_cast(unsigned, (s2v)(x * y));
+            // the cross term is signed: + 64 * 256 makes both digits unsigned (one v_pk_mad_u16), the 64 comes off below
+            q[v] = __builtin_bit_cast(unsigned, s == 4 ? (s2v)(x * y + s2v{0x4000, 0x4000}) : (s2v)(x * y));
           }
-          {  // low digit: byte 0 of each 16-bit product, in [0, 255], as f16 1024 + digit (bias in the accumulator's start)
+          {  // low digit: byte 0 of each 16-bit product
 #pragma unroll
-            for (int v = 0; v < 4; ++v) t[v] = __builtin_amdgcn_perm(0x64646464u, q[v], 0x04020400u);
+            for (int v = 0; v < 4; ++v) t[v] = __builtin_amdgcn_perm(0u, q[v], 0x0c020c00u);
             const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-            PQA_MMA0(D[s][b], FRAG_LO0, bias4); PQA_MMA(D[s][b], FRAG_LO0 + 1);
+            PQA_MMA0(D[s][b], 3, zero4); PQA_MMA(D[s][b], 4);
           }
-          {  // high digit: byte 1; the cross term is signed: bias by 64 * 256 first, take the bias off as f16
+          {  // high digit: byte 1
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-              t[v] = s == 4 ? f16_pair_from_byte_of_halves(
-                                  __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, q[v]) + s2v{0x4000, 0x4000}), 1, 1088.0f)
-                            : f16_pair_from_byte_of_halves(q[v], 1, 1024.0f);
+            for (int v = 0; v < 4; ++v) {
+              t[v] = __builtin_amdgcn_perm(0u, q[v], 0x0c030c01u);
+              if (s == 4) t[v] = f16_tiny_minus(t[v], 0x8040);   // - 64 * 2^-24
+            }
             const h8 B = frag_from(t[0], t[1], t[2], t[3]);
             PQA_MMA(D[s][b], 0); PQA_MMA(D[s][b], 1); PQA_MMA(D[s][b], 2);
           }
@@ -699,16 +712,14 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
             const int y0_ = (int)(short)(ys & 0xffffu), y1_ = (int)ys >> 16;
             const int add = s == 4 ? (256 << 10) : 0;
             const unsigned p0 = (unsigned)(x0_ * y0_ + add), p1 = (unsigned)(x1_ * y1_ + add);
-            // {1024 + lo(p1), 1024 + lo(p0)} and {1024 + hi(p1), 1024 + hi(p0)} as f16 bit patterns (v_bfi_b32)
-            const unsigned l = bfi32(0x03ff0000u, p1 << 16, bfi32(0x3ffu, p0, 0x64006400u));
-            const unsigned hgh = bfi32(0x03ff0000u, p1 << 6, bfi32(0x3ffu, p0 >> 10, 0x64006400u));
-            lo_[v] = l;
-            const float hb = s == 4 ? 1280.0f : 1024.0f;
-            hi_[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, hgh) - h2{(_Float16)hb, (_Float16)hb});
+            // {lo(p1), lo(p0)} and {hi(p1), hi(p0)} in the 16-bit halves (v_bfi_b32)
+            lo_[v] = bfi32(0x03ff0000u, p1 << 16, p0 & 0x3ffu);
+            const unsigned hgh = bfi32(0x03ff0000u, p1 << 6, p0 >> 10);
+            hi_[v] = s == 4 ? f16_tiny_minus(hgh, 0x8100) : hgh;   // - 256 * 2^-24
           }
           {
             const h8 B = frag_from(lo_[0], lo_[1], lo_[2], lo_[3]);
-            PQA_MMA0(D[s][b], FRAG_LO0, bias4); PQA_MMA(D[s][b], FRAG_LO0 + 1);
+            PQA_MMA0(D[s][b], 3, zero4); PQA_MMA(D[s][b], 4);
           }
           {
             const h8 B = frag_from(hi_[0], hi_[1], hi_[2], hi_[3]);
@@ -721,15 +732,22 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
     }
     // upper tile -> LDS (registers 0,1 = rows 2g, 2g+1), lower tile's half parked
 #pragma unroll
+    // (one 8-byte store per N-block: an accumulator's registers {0,1} are adjacent, the two N-blocks' are not -- a
+    // 16-byte store would first copy them together, and a copy costs the VALU as much as a packed FMA)
     for (int s = 0; s < 5; ++s) {
-      if (s < 2) {  // the means carry 2^19, the squares 2^11: bring them to the common 2^11 (exact)
-        D[s][0] *= kMfmaMuScale;
-        D[s][1] *= kMfmaMuScale;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        lds_store_f2(&sv[s][g][col0 + b], f2{D[s][b][0], D[s][b][1]});
+        park[pass][s][b] = f2{D[s][b][2], D[s][b][3]};
       }
-      *reinterpret_cast<f4*>(&sv[s][g][col0]) = f4{D[s][0][0], D[s][0][1], D[s][1][0], D[s][1][1]};
-      park[pass][s] = f4{D[s][0][2], D[s][0][3], D[s][1][2], D[s][1][3]};
     }
-    *reinterpret_cast<f4*>(&sd[g][col0]) = f4{Dd[0][0][0], Dd[1][0][0], Dd[0][1][0], Dd[1][1][0]};
+    // (the decimation row's four values sit in four accumulators: four 4-byte stores instead of four copies + one store)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float* slot = reinterpret_cast<float*>(&sd[g][col0 + b]);
+      lds_store_f32(slot, Dd[0][b][0]);
+      lds_store_f32(slot + 1, Dd[1][b][0]);
+    }
     park_d[pass] = f4{Dd[0][0][1], Dd[1][0][1], Dd[0][1][1], Dd[1][1][1]};
     if (MOTION) {
       *reinterpret_cast<f4*>(&sv[5][g][col0]) = f4{Dm[0][0], Dm[0][1], Dm[1][0], Dm[1][1]};
@@ -747,7 +765,10 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
   for (int pass = 0; pass < 2; ++pass) {
     const int col0 = 64 * wave + 32 * pass + 2 * n;
 #pragma unroll
-    for (int s = 0; s < 5; ++s) *reinterpret_cast<f4*>(&sv[s][g][col0]) = park[pass][s];
+    for (int s = 0; s < 5; ++s) {
+      lds_store_f2(&sv[s][g][col0], park[pass][s][0]);
+      lds_store_f2(&sv[s][g][col0 + 1], park[pass][s][1]);
+    }
     *reinterpret_cast<f4*>(&sd[g][col0]) = park_d[pass];
     if (MOTION) *reinterpret_cast<f4*>(&sv[5][g][col0]) = park_m[pass];
   }
@@ -759,20 +780,6 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
 // of the 16-row tile pair (see the kernel comment); K index k = 8 (lane >> 4) + j is input row k - 8 relative to the
 // pair's first row.  The decimation band puts even output row 2 gg of the upper (i = 0) / lower (i = 1) tile in
 // registers 0 / 1 and leaves 2, 3 empty.
-static double lo_band_sum(double scale) {  // sum over the 17 taps of the two f16 pieces of c * scale (what the low digit planes see)
-  const Taps c17 = gaussian_taps(17);
-  double s = 0.0;
-  for (int t = 0; t < 17; ++t) {
-    double r = (double)c17.f[t] * scale;
-    for (int p = 0; p < 2; ++p) {
-      const _Float16 h = (_Float16)r;
-      s += (double)h;
-      r -= (double)h;
-    }
-  }
-  return s;
-}
-
 static bool build_atab(uint16_t* out /* [kAtabFrags][64][8] */) {
   const Taps c17 = gaussian_taps(17), c9 = gaussian_taps(9);
   float c5[5];
@@ -799,7 +806,14 @@ static bool build_atab(uint16_t* out /* [kAtabFrags][64][8] */) {
         return r;
       };
       if (pieces(c * 524288.0, 3, 0) != 0.0) exact = false;
-      pieces(c * 2048.0, 2, 3);
+      {  // c * 2^11: three pieces, exact (the last one may be an f16 denormal); the low digit planes use the first two
+        double r = pieces(c * 2048.0, 2, 3);
+        const _Float16 h = (_Float16)r;
+        uint16_t bits;
+        memcpy(&bits, &h, 2);
+        out[((size_t)12 * 64 + lane) * 8 + j] = bits;
+        if (r - (double)h != 0.0) exact = false;
+      }
       if (pieces(cd * 262144.0, 3, 5) != 0.0) exact = false;
       pieces(c * 512.0, 2, 8);
       const int t5 = k - (row + 6);   // motion: output row y blurs input rows y + 6 .. y + 10 of the 32-row window
@@ -854,11 +868,11 @@ bool launch_s0_split(hipStream_t stream, bool ten_bit, const VifStatArgs& base, 
   VifStatArgs m = base;
   m.atab = device_atab();
   if (!m.atab) return false;
-  static const float lo_bias8 = (float)(-1024.0 * lo_band_sum(2048.0)), lo_bias10 = (float)(-1024.0 * lo_band_sum(512.0));
-  m.lo_bias = ten_bit ? lo_bias10 : lo_bias8;
-  // the vertical pass leaves 2^11 x the 8-bit signals (2^13 x the 10-bit ones: 2^9 from the tap pieces, 4^2 from the
-  // sample scale) and 2^18 (2^20) x the next scale's input: exact powers of two, folded into the horizontal taps
-  const float sq = ten_bit ? kMfmaSqScale * 0.25f : kMfmaSqScale, dec = ten_bit ? kMfmaDecScale * 0.25f : kMfmaDecScale;
+  // the vertical pass leaves every signal of an 8-bit clip times 2^-13 (operands k * 2^-24, tap pieces c * 2^11, or
+  // c * 2^19 on the digits that weigh 2^8) and the next scale's input times 2^-6; for 10-bit clips (x = (v - 512) / 4,
+  // digits base 1024) the same operands give 2^-11 and 2^-4 of the scaled signals.  Exact powers of two, folded into
+  // the horizontal taps.
+  const float sq = ten_bit ? 2048.0f : 8192.0f, dec = ten_bit ? 16.0f : 64.0f;
   for (int k = 0; k < 17; ++k) m.taps.ht[k] = f2{base.taps.ht[k].x * sq, base.taps.ht[k].y * sq};
   for (int k = 0; k < 9; ++k) m.taps.dt[k] = f2{base.taps.dt[k].x * dec, base.taps.dt[k].y * dec};
   // Fused motion is an OPT-IN experiment (PQA_FUSE_MOTION=1), off by default because it LOSES: measured at 2160p the
