@@ -134,17 +134,21 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
   // ---- 1b. fused decimation: horizontal pass at even columns, written straight to the next scale --
   if (ND) {
     const int ox0 = x0 >> 1, oy0 = y0 >> 1, ow = a.w >> 1, oh = a.h >> 1;
+    // the tile's first output sample as a scalar address, the thread's place inside the tile as a 32-bit offset
+    // in BYTES (global_store with an SGPR base and a 32-bit VGPR offset: no 64-bit VALU arithmetic; a tile spans 4 rows)
+    float* __restrict__ tr = a.dst_ref + ((int64_t)fr * a.dst_frame_pitch_r + (int64_t)oy0 * a.dst_row_pitch_r + ox0);
+    float* __restrict__ td = a.dst_dis + ((int64_t)fr * a.dst_frame_pitch_d + (int64_t)oy0 * a.dst_row_pitch_d + ox0);
+    const unsigned rp_r = (unsigned)a.dst_row_pitch_r, rp_d = (unsigned)a.dst_row_pitch_d;
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
       const int item = tid + round * kBlock;
       const int oc = item & 127, orow = item >> 7;  // 128 slots per row, TW/2 of them used
-      const int gx = ox0 + oc, gy = oy0 + orow;
-      if (oc < TW / 2 && (FULL || (gx < ow && gy < oh))) {
+      if (oc < TW / 2 && (FULL || (ox0 + oc < ow && oy0 + orow < oh))) {
         f2 acc = f2{0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < ND; ++k) acc = __builtin_elementwise_fma(a.taps.dt[k], sd[orow * kP2 + 2 * oc + (R - RD) + k], acc);
-        a.dst_ref[(int64_t)fr * a.dst_frame_pitch_r + (int64_t)gy * a.dst_row_pitch_r + gx] = acc.x;
-        a.dst_dis[(int64_t)fr * a.dst_frame_pitch_d + (int64_t)gy * a.dst_row_pitch_d + gx] = acc.y;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(tr) + ((unsigned)orow * rp_r + (unsigned)oc) * 4u) = acc.x;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(td) + ((unsigned)orow * rp_d + (unsigned)oc) * 4u) = acc.y;
       }
     }
   }
@@ -401,31 +405,36 @@ __global__ __launch_bounds__(kBlock, 3) void vif_stat_kernel(const VifStatArgs a
 
 
 // ================================================================================================================
-// Scale 0 of 8-bit clips on the matrix cores: the 17-tap VERTICAL pass as a banded-Toeplitz product with exact inputs.
+// Scale 0 of 8-bit and 10-bit clips on the matrix cores: the 17-tap VERTICAL pass as a banded-Toeplitz product with exact inputs.
 //
-// Why.  The VALU kernel above is bound by FP32 FMA throughput (64 FLOP/clk/SIMD, the same through v_pk_fma_f32, plain
-// v_fma_f32 and the f32 MFMA forms -- and packed FP32 shares its pipe with MFMA: tools/ubench/mfma_coissue.hip,
-// pk_vs_plain.hip); its vertical pass + sample conversion is 42 % of its issue cycles.  The f16 matrix pipe has 16x that
-// rate, and at scale 0 the filter INPUTS are small integers, so they can go through it without loss:
+// Why.  The VALU kernel above is bound by VALU issue cycles: FP32 FMA throughput is 64 FLOP/clk/SIMD however it is
+// issued (v_pk_fma_f32 every 4 clocks, plain v_fma_f32 every 2, the f32 MFMA forms), FMAs of either kind share their
+// pipe with MFMA, and every other VALU instruction (convert, select, max, byte permute, copy) takes the 4 clocks of a
+// packed FMA, about half of which an MFMA of another wave can hide (tools/ubench/mfma_coissue.hip, pk_vs_plain.hip,
+// mfma_plain_coissue.hip).  Its vertical pass + sample conversion is 42 % of its issue cycles.  The f16 matrix pipe has
+// 16x the FMA rate, and at scale 0 the filter INPUTS are small integers, so they can go through it without loss:
 //   * the five signals are split into base-256 digit planes of exact integers: r' = r-128, d' = d-128 (|.| <= 128);
 //     r'^2, d'^2 in [0, 16384] -> hi, lo with value = 256 hi + lo; r'd' in [-16256, 16384] -> hi = floor(./256) in
-//     [-64, 64], lo in [0, 255].  Every digit is exact in f16 (11-bit significand);
-//   * every f32 tap c is split into three f16 pieces of c * 2^19 (11 + 11 + 2 bits: exact, checked on the host; the
-//     2^19 keeps every piece a normal f16, the largest is 62 272 < 65 504).  Low digit planes use the first two pieces
-//     of c * 2^11 (22 bits: their weight is 2^-8 of the signal);
+//     [-64, 64], lo in [0, 255];
+//   * an integer k < 2048 in a 16-bit lane already IS an f16 -- the bit pattern reads as k * 2^-24 (denormals and the
+//     first normal binade share one ulp) -- so a digit costs the one byte permute that extracts it and no conversion;
+//     signed planes (r', d', the cross term's high digit) take one v_pk_add_f16 of the offset, exact;
+//   * every f32 tap c is split into three f16 pieces, exactly (checked on the host): c * 2^19 for the digits that
+//     weigh 2^8 (the largest piece is 62 272 < 65 504) and c * 2^11 for the mean planes; the low digit planes use the
+//     first two pieces of c * 2^11 (22 bits: their weight is 2^-8 of the signal);
 //   * v_mfma_f32_16x16x32_f16: D[16 out rows][16 cols] += A[16][32 input rows] * B[32][16]; f16 x f16 products are
 //     exact in f32, the accumulator is f32.  A = the Toeplitz band of tap pieces (per-lane constants from a table),
 //     B = a digit plane.  16 output rows need exactly the 32 input rows one instruction holds.
-// The result is 2^11 (squares) / 2^19 (means) times the f32 convolution with an error below one f32 rounding of
-// libvmaf's own tap-by-tap sum; the factors are folded into the horizontal taps (exact powers of two).  The next
-// scale's input (9-tap filter, even rows) rides the same B operands with its own band matrix.
+// Every signal comes out as 2^-13 times the f32 convolution with an error below one f32 rounding of libvmaf's own
+// tap-by-tap sum; the factor is folded into the horizontal taps (an exact power of two).  The next scale's input
+// (9-tap filter, even rows) rides the mean planes' B operands with its own band matrix.
 //
 // Shape.  One workgroup = two vertically adjacent tiles of the VALU kernel's grid (TW x 16 outputs, 32 input rows).
 // Wave w owns input columns 64w..64w+63 in two passes of 32; lane l: n = l & 15 -> columns 2n, 2n+1 (one 16-bit load
 // per row: N-blocks b = 0, 1), g = l >> 4 -> input rows 8g..8g+7 (the K group of the B operand).  The output rows
 // are permuted in A so that accumulator registers {0,1} of lane group g are rows {2g, 2g+1} of the UPPER tile and
-// {2,3} the same rows of the LOWER tile: one ds_write_b128 per signal stores {row 2p, row 2p+1} x 2 columns in the
-// layout vif_hstat reads, conflict-free; the lower tile's half waits in registers while the upper tile runs its
+// {2,3} the same rows of the LOWER tile: one ds_write_b64 per signal and N-block stores {row 2p, row 2p+1} of a column
+// in the layout vif_hstat reads; the lower tile's half waits in registers while the upper tile runs its
 // horizontal pass + statistic, then takes its place in LDS (the LDS holds one 8-row tile: 3 workgroups per CU).
 // Only tiles whose 32 x 256 input window lies inside the image take this path (no mirroring: 86 % of the tiles at
 // 2160p, 72 % at 1080p); border tiles run vif_stat_kernel<.., EDGE>.  Both write the same per-tile partials.
@@ -473,8 +482,9 @@ __device__ __forceinline__ unsigned f16_tiny_minus(unsigned x, unsigned short of
 
 // T = uint8_t: 8-bit samples as described above.  T = uint16_t: 10-bit samples (libvmaf: x = v / 4 - 128 = (v - 512) / 4):
 // v - 512 is one exact f16 plane, the squares (<= 2^18) and the cross term split into base-1024 digits (hi <= 256,
-// lo < 1024: both exact in f16) from 32-bit products; the low planes use pieces of c * 2^9, the powers of four of the
-// sample scale go into the horizontal taps.  12-bit clips (squares of 22 bits: three digits) stay on the VALU kernel.
+// lo < 1024: still below 2048) from 32-bit products; the low planes use pieces of c * 2^9, and with the sample scale
+// (1/4 on the means, 1/16 on the squares) every signal comes out as 2^-11 of libvmaf's: again one factor for the
+// horizontal taps.  12-bit clips (squares of 22 bits: three digits) stay on the VALU kernel.
 // MOTION (opt-in experiment, PQA_FUSE_MOTION=1; slower than the standalone motion kernel, see launch_s0_split): the motion
 // feature rides along as a sixth plane -- the exact integer frame difference of the reference luma (|.| <= 255 / 1023: one
 // f16 plane), its 5-tap vertical blur as two more MFMAs per N-block (two-piece taps x 2^17), the horizontal blur and the
