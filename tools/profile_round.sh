@@ -13,19 +13,20 @@ mkdir -p "$OUT" "$RAW"
 export TMPDIR=/tmp
 cd /tmp
 say() { echo "$(date +%T) $*" | tee -a "$OUT/progress.log"; }
-T="timeout -k 10 75"
+failed() { say "the $1 counter pass failed or timed out: its figures will be missing; last lines of its stderr:"; tail -n 6 "$RAW/$1.err" | cut -c1-300 | tee -a "$OUT/progress.log"; }
+T="timeout -k 10 ${PQA_PROF_TIMEOUT:-75}"
 # 96 frames = three full launches of 32 (frames per launch is then exact); short, so a profiler stall costs little
 FRAMES=96
 B="$R/bench.py --workload $WL --steps 2 --warmup 1 --frames $FRAMES --no-cpu-baseline --no-other-configs --no-e2e"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -- python3 $B > "$OUT/${TAG}_bench_${WL}_under_rocprof.json" 2> "$RAW/stats.err"
 say "stats pass done"
-$T rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$RAW/fetch" -- python3 $B > /dev/null 2> "$RAW/fetch.err" || say "a counter pass failed or timed out (see above): its figures will be missing"
+$T rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$RAW/fetch" -- python3 $B > /dev/null 2> "$RAW/fetch.err" || failed fetch
 say "fetch pass done"
-$T rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$RAW/write" -- python3 $B > /dev/null 2> "$RAW/write.err" || say "a counter pass failed or timed out (see above): its figures will be missing"
+$T rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$RAW/write" -- python3 $B > /dev/null 2> "$RAW/write.err" || failed write
 say "traffic passes done"
-$T rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d "$RAW/sqa" -- python3 $B > /dev/null 2> "$RAW/sqa.err" || say "a counter pass failed or timed out (see above): its figures will be missing"
+$T rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d "$RAW/sqa" -- python3 $B > /dev/null 2> "$RAW/sqa.err" || failed sqa
 say "SQ pass A done"
-$T rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE -d "$RAW/sqb" -- python3 $B > /dev/null 2> "$RAW/sqb.err" || say "a counter pass failed or timed out (see above): its figures will be missing"
+$T rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE -d "$RAW/sqb" -- python3 $B > /dev/null 2> "$RAW/sqb.err" || failed sqb
 say "SQ passes done"
 BATCH=$(python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['config']['batch'])" "$OUT/${TAG}_bench_${WL}_under_rocprof.json")
 # frames per launch averaged over all launches (the last batch of a 300-frame clip is partial)
