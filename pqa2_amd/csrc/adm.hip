@@ -57,20 +57,17 @@ __device__ __forceinline__ f2 med3_2(f2 a, f2 b, f2 c) {
 // adjacent coefficients of the same column.  The vertical pass produces {ref, dis} pairs (one packed FMA
 // per tap for both images) and re-pairs them by rows when it stores to LDS, so the horizontal DWT reads
 // natural row pairs and the whole decouple / CSF / masking chain runs packed on two coefficients.
-template <typename T>
-__global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
-  __shared__ f2 V[4][NRP][VP];  // 0 lo(ref) 1 hi(ref) 2 lo(dis) 3 hi(dis); {row 2p, row 2p+1}
-  __shared__ float G[GH][GP];   // masking signal: sum over orientations of |csf(a)| / 30
-  __shared__ double red[24];
-
+// LLONLY: the tile has no coefficient inside the accumulation window (libvmaf crops 10 % on every side: a third of the
+// tiles of a frame).  Its six sums are zero by definition; all it owes is its piece of the approximation bands the next
+// scale reads: the low band of the vertical pass, two of the eight horizontal filters, no decouple / CSF / masking.
+template <typename T, bool LLONLY>
+__device__ __forceinline__ void adm_tile(const AdmArgs& a, f2 (*V)[NRP][VP], float (*G)[GP], double* red, int tile, int tx,
+                                         int ty, int fr) {
   const float lo0 = 0.482962913144690f, lo1 = 0.836516303737469f, lo2 = 0.224143868041857f,
               lo3 = -0.129409522550921f;
   const float hi0 = -0.129409522550921f, hi1 = -0.224143868041857f, hi2 = 0.836516303737469f,
               hi3 = -0.482962913144690f;
 
-  const int tile = xcd_remap(blockIdx.x, a.n_tiles);
-  const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-  const int fr = blockIdx.y;
   const T* __restrict__ ref = (const T*)a.ref + (int64_t)fr * a.frame_pitch_r;
   const T* __restrict__ dis = (const T*)a.dis + (int64_t)fr * a.frame_pitch_d;
   const int cx0 = tx * TW, cy0 = ty * TH;
@@ -116,21 +113,26 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
         for (int e = 0; e < 2; ++e) {
           const int o = 2 * p + e;
           // taps accumulate in libvmaf's order: ((c0*s0 + c1*s1) + c2*s2) + c3*s3
-          f2 l = splat(lo0) * x[2 * o], h = splat(hi0) * x[2 * o];
+          f2 l = splat(lo0) * x[2 * o];
           l = __builtin_elementwise_fma(splat(lo1), x[2 * o + 1], l);
-          h = __builtin_elementwise_fma(splat(hi1), x[2 * o + 1], h);
           l = __builtin_elementwise_fma(splat(lo2), x[2 * o + 2], l);
-          h = __builtin_elementwise_fma(splat(hi2), x[2 * o + 2], h);
           l = __builtin_elementwise_fma(splat(lo3), x[2 * o + 3], l);
-          h = __builtin_elementwise_fma(splat(hi3), x[2 * o + 3], h);
           vl[e] = l;
-          vh[e] = h;
+          if (!LLONLY) {
+            f2 h = splat(hi0) * x[2 * o];
+            h = __builtin_elementwise_fma(splat(hi1), x[2 * o + 1], h);
+            h = __builtin_elementwise_fma(splat(hi2), x[2 * o + 2], h);
+            h = __builtin_elementwise_fma(splat(hi3), x[2 * o + 3], h);
+            vh[e] = h;
+          }
         }
         const int rp = strip * (SROWS / 2) + p;
         V[0][rp][col] = f2{vl[0].x, vl[1].x};
-        V[1][rp][col] = f2{vh[0].x, vh[1].x};
         V[2][rp][col] = f2{vl[0].y, vl[1].y};
-        V[3][rp][col] = f2{vh[0].y, vh[1].y};
+        if (!LLONLY) {
+          V[1][rp][col] = f2{vh[0].x, vh[1].x};
+          V[3][rp][col] = f2{vh[0].y, vh[1].y};
+        }
       }
     }
   }
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
     f2 s[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      if (LLONLY && (q & 1)) continue;   // the high vertical bands were not produced
       const f4* p = reinterpret_cast<const f4*>(&V[q][rp][2 * lcxs]);
       const f4 v01 = p[0], v23 = p[1];
       s[q][0] = f2{v01.x, v01.y}; s[q][1] = f2{v01.z, v01.w};
@@ -169,14 +172,7 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
   __builtin_elementwise_fma(splat(c3), t[3],                                                              \
                             __builtin_elementwise_fma(splat(c2), t[2], __builtin_elementwise_fma(splat(c1), t[1], splat(c0) * t[0])))
     const f2 ra = PQA_DWT(lo0, lo1, lo2, lo3, s[0]);  // reference approximation, rows {A, B}
-    const f2 ov = PQA_DWT(hi0, hi1, hi2, hi3, s[0]);  // vertical   (lo-v, hi-h)
-    const f2 oh = PQA_DWT(lo0, lo1, lo2, lo3, s[1]);  // horizontal (hi-v, lo-h)
-    const f2 od = PQA_DWT(hi0, hi1, hi2, hi3, s[1]);  // diagonal
     const f2 da = PQA_DWT(lo0, lo1, lo2, lo3, s[2]);
-    const f2 tv = PQA_DWT(hi0, hi1, hi2, hi3, s[2]);
-    const f2 th = PQA_DWT(lo0, lo1, lo2, lo3, s[3]);
-    const f2 td = PQA_DWT(hi0, hi1, hi2, hi3, s[3]);
-#undef PQA_DWT
     const bool vA = col_valid && cyA >= 0 && cyA < a.oh, vB = col_valid && cyB >= 0 && cyB < a.oh;
     const bool iA = col_inner && lcyA >= 1 && cyA < a.oh;                    // lcyA <= TH always (lcyA <= GH-2)
     const bool iB = col_inner && lcyA + 1 <= TH && cyB >= 0 && cyB < a.oh;   // lcyA + 1 >= 1 always
@@ -192,6 +188,14 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
         ld[(unsigned)cyB * (unsigned)a.ll_row_pitch_d + (unsigned)cx] = da.y;
       }
     }
+    if (LLONLY) continue;
+    const f2 ov = PQA_DWT(hi0, hi1, hi2, hi3, s[0]);  // vertical   (lo-v, hi-h)
+    const f2 oh = PQA_DWT(lo0, lo1, lo2, lo3, s[1]);  // horizontal (hi-v, lo-h)
+    const f2 od = PQA_DWT(hi0, hi1, hi2, hi3, s[1]);  // diagonal
+    const f2 tv = PQA_DWT(hi0, hi1, hi2, hi3, s[2]);
+    const f2 th = PQA_DWT(lo0, lo1, lo2, lo3, s[3]);
+    const f2 td = PQA_DWT(hi0, hi1, hi2, hi3, s[3]);
+#undef PQA_DWT
     // decouple + enhancement-gain limit.  libvmaf computes k = clamp(t / (o + eps), 0, 1), r = k * o and, where the angle
     // between (o_h, o_v) and (t_h, t_v) is below one degree, r = min(r * limit, t) for r > 0 / max(r * limit, t) for r < 0.
     // In exact arithmetic k * o is
@@ -235,6 +239,10 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
       G[lcyA][lcx] = vA ? gA : 0.0f;
       G[lcyA + 1][lcx] = vB ? gB : 0.0f;
     }
+  }
+  if (LLONLY) {
+    if (tid < 6) a.partials[((int64_t)fr * a.n_tiles + tile) * 6 + tid] = 0.0;
+    return;
   }
   __syncthreads();
 
@@ -289,6 +297,28 @@ __global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
     double* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * 6;
 #pragma unroll
     for (int i = 0; i < 6; ++i) out[i] = v[i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock, 4) void adm_scale_kernel(const AdmArgs a) {
+  __shared__ f2 V[4][NRP][VP];  // 0 lo(ref) 1 hi(ref) 2 lo(dis) 3 hi(dis); {row 2p, row 2p+1}
+  __shared__ float G[GH][GP];   // masking signal: sum over orientations of |csf(a)| / 30
+  __shared__ double red[24];
+  const int tile = xcd_remap(blockIdx.x, a.n_tiles);
+  const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+  const int fr = blockIdx.y;
+  const int cx0 = tx * TW, cy0 = ty * TH;
+  // no inner coefficient of this tile inside [left, right) x [top, bottom)?  (workgroup-uniform)
+  const bool outside = !(cx0 < a.right && cx0 + TW > a.left && cy0 < a.bottom && cy0 + TH > a.top);
+  if (outside) {
+    if (!a.ll_ref) {   // last scale: nothing to produce at all
+      if (threadIdx.x < 6) a.partials[((int64_t)fr * a.n_tiles + tile) * 6 + threadIdx.x] = 0.0;
+      return;
+    }
+    adm_tile<T, true>(a, V, G, red, tile, tx, ty, fr);
+  } else {
+    adm_tile<T, false>(a, V, G, red, tile, tx, ty, fr);
   }
 }
 
