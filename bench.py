@@ -224,7 +224,7 @@ def main():
                                # SURVEY 8(d)'s primary formula for the WHOLE path: frames/s x B_alg / HBM peak
                                "pipeline_frac": round(fps / world * b_alg / (HBM_PEAK_GBS * 1e9), 5),
                                # what actually limits the kernel: FP32 issue, not bytes
-                               "measured_limiter": "valu-issue (FP32 FMA rate), not HBM: see `valu`"}
+                               "measured_limiter": "VALU issue cycles (FP32 FMA rate + 4-clock non-FMA instructions) and the matrix pipe they share, not HBM: see `valu`, `mfma`"}
             if cnt.get("valu_insts_per_wave"):
                 # issue floor = VALU instructions per wave x waves / (1024 SIMDs x one wave64 instruction per 4 clocks)
                 clk = cnt.get("shader_clock_ghz", 2.0)
@@ -236,9 +236,11 @@ def main():
                     "valu_wave_insts_per_frame": int(wave_insts),
                     "shader_clock_ghz": clk, "issue_floor_us_per_frame": round(floor_us, 2),
                     "measured_us_per_frame": round(meas_us, 2), "frac": round(floor_us / meas_us, 4),
-                    "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk (v_pk_fma_f32 = 2 FMA per lane: 157 TFLOP/s); plain "
-                                 "(unpacked) VALU issues in 2 clk with >= 2 waves per SIMD and the 108 MFMAs per wave hold the pipe "
-                                 "16 clk each (profiles/r02a_ubench_*.txt), so this is a count-based floor, not a cycle model",
+                    "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk: what v_pk_fma_f32 (2 FMA per lane: 157 TFLOP/s) AND "
+                                 "every non-FMA instruction (convert, select, permute, copy) cost; plain v_fma_f32 takes about 2 clk; "
+                                 "SQ_INSTS_VALU counts the 108 MFMAs per wave too, which hold the pipe 16 clk each with about half "
+                                 "of that hidden under non-FMA VALU work (profiles/r02a_ubench_*.txt, r02j_ubench_mfma_plain_coissue.txt): "
+                                 "a count-based floor, not a cycle model",
                     "source": cnt.get("valu_source")}
             if bpc <= 10 and not args.fixed_point:
                 # matrix-core share of the same launches: 108 v_mfma_f32_16x16x32_f16 (16384 FLOP each) per wave and
