@@ -20,6 +20,7 @@
 #include <mutex>
 #include <vector>
 
+#include <cstdio>
 #include "kernels.h"
 #include "pqa_device.h"
 
@@ -786,6 +787,23 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
   vif_hstat<N, TW, ND, !EDGE, MOTION>(a, &sv[0][0][0], &sd[0][0], red, fr, (ty + 1) * a.tiles_x + tx, x0, y0 + TH);
 }
 
+// The operand encoding above leans on f16 denormals surviving v_pk_add_f16 and the MFMA's B operand.  gfx950 keeps them
+// (measured), but it is a property of the device and of the kernel's float mode, so every process checks it once before the
+// matrix-core kernel is allowed to run: column n of B holds the pattern k = 67 n + 1 (minus 1 via the packed add), A is all
+// ones -> D[.][n] = 32 (k - 1) 2^-24 exactly.  ok[0] counts the lanes that saw that.
+__global__ void f16_tiny_probe_kernel(int* ok) {
+  const int lane = threadIdx.x, n = lane & 15;
+  const unsigned k = ((unsigned)n * 67u + 1u) & 0x3ffu;
+  const unsigned t = f16_tiny_minus(k | (k << 16), 0x8001);   // (k - 1) * 2^-24 in both halves
+  const h8 b = frag_from(t, t, t, t);
+  h8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (_Float16)1.0f;
+  const f4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, f4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+  const float want = 32.0f * (float)(k - 1u) * 5.9604644775390625e-08f;   // 2^-24
+  if (d[0] == want && d[3] == want) atomicAdd(ok, 1);
+}
+
 // Host: the per-lane A fragments.  Row m = lane & 15 = 4 gg + i of the product is output row 8 (i >> 1) + 2 gg + (i & 1)
 // of the 16-row tile pair (see the kernel comment); K index k = 8 (lane >> 4) + j is input row k - 8 relative to the
 // pair's first row.  The decimation band puts even output row 2 gg of the upper (i = 0) / lower (i = 1) tile in
@@ -951,6 +969,29 @@ hipError_t vif_mfma_prepare() {
   if ((e = hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) {
     (void)hipFree(d);
     return e;
+  }
+  {  // the probe (see f16_tiny_probe_kernel): without kept denormals scale 0 stays on the VALU kernel, and says so once
+    int* ok = nullptr;
+    int seen = 0;
+    if ((e = hipMalloc((void**)&ok, sizeof(int))) == hipSuccess) {
+      e = hipMemset(ok, 0, sizeof(int));
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(f16_tiny_probe_kernel, dim3(1), dim3(64), 0, 0, ok);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpy(&seen, ok, sizeof(int), hipMemcpyDeviceToHost);
+      (void)hipFree(ok);
+    }
+    if (e != hipSuccess) {
+      (void)hipFree(d);
+      return e;
+    }
+    if (seen != 64) {
+      fprintf(stderr, "pqa_vmaf: device %d does not keep f16 denormals (%d of 64 probe lanes exact): VIF scale 0 runs the "
+                      "VALU kernel instead of the matrix-core kernel\n", dev, seen);
+      (void)hipFree(d);
+      return hipSuccess;
+    }
   }
   g_atab[dev] = (const uint4*)d;   // lives as long as the process (8 KB per device)
   return hipSuccess;
