@@ -700,7 +700,7 @@ void copy_plane_rows(uint8_t* dst, int64_t dst_pitch, const uint8_t* src, int64_
 // ================================================================================================
 extern "C" {
 
-const char* pqa_version(void) { return "pqa_vmaf 0.1.0 (gfx950; libvmaf-float VIF/ADM/motion, FFmpeg psnr/ssim)"; }
+const char* pqa_version(void) { return "pqa_vmaf 0.2.0 (gfx950; libvmaf-float VIF/ADM/motion, FFmpeg psnr/ssim; VIF scale 0 on the f16 matrix cores)"; }
 int pqa_record_doubles(void) { return PQA_RECORD_DOUBLES; }
 
 void pqa_config_init(pqa_config* cfg, uint32_t width, uint32_t height) {

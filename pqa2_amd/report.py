@@ -11,7 +11,7 @@ import numpy as np
 
 from .model import pool
 
-ENGINE_VERSION = "pqa2_amd-0.1.0"
+ENGINE_VERSION = "pqa2_amd-0.2.0"
 
 
 def _f6(x: float) -> str:
