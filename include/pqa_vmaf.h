@@ -148,6 +148,31 @@ PQA_API int pqa_submit(pqa_ctx* ctx, int64_t frame_index, const void* const ref_
 PQA_API int pqa_submit_device(pqa_ctx* ctx, int64_t first_index, int32_t n_frames, const pqa_device_clip* ref,
                       const pqa_device_clip* dis, const void* prev_ref_luma, int64_t prev_row_pitch);
 
+/* Decoder surfaces in device memory: what a hardware decoder (VCN through rocDecode / VA-API) writes and what a drop-in
+ * that keeps decode on the GPU hands over instead of the planes ffmpeg would feed libvmaf (app/vmaf_analyzer.py:415-416
+ * names the two inputs).  NV12: 8-bit Y plane + ONE plane of interleaved U,V pairs at half
+ * resolution in both directions.  P01X: the same layout with 16-bit little-endian samples whose value sits in the UPPER
+ * bit_depth bits (P010 for a 10-bit context, P012 for a 12-bit one).  Frame f's planes start at luma + f * luma_frame_pitch
+ * and chroma + f * chroma_frame_pitch; pitches in BYTES.  chroma may be NULL when the context has n_planes == 1. */
+enum { PQA_SURFACE_NV12 = 1, PQA_SURFACE_P01X = 2 };
+typedef struct pqa_surface_clip {
+  uint32_t struct_size;        /* sizeof(pqa_surface_clip) */
+  uint32_t format;             /* PQA_SURFACE_* */
+  const void* luma;
+  const void* chroma;
+  int64_t luma_row_pitch, luma_frame_pitch;
+  int64_t chroma_row_pitch, chroma_frame_pitch;
+} pqa_surface_clip;
+
+/* Submit n_frames consecutive frame pairs held as decoder surfaces.  An NV12 luma plane is scored where it lies;
+ * interleaved chroma is split into planes and 16-bit samples are shifted down on the way (device-side, into the
+ * context's own staging; nothing crosses PCIe).  The context must be 4:2:0 (chroma shifts 1, 1) when n_planes == 3.
+ * prev_ref (nullable) carries, as its frame 0, the reference frame first_index-1 -- the motion halo of a frame-sharded
+ * rank; NULL continues from the last frame the context saw, as pqa_submit_device does.  Same record semantics as the
+ * other submit calls. */
+PQA_API int pqa_submit_surfaces(pqa_ctx* ctx, int64_t first_index, int32_t n_frames, const pqa_surface_clip* ref,
+                                const pqa_surface_clip* dis, const pqa_surface_clip* prev_ref);
+
 /* Host-memory variant of the halo for the pqa_submit path. */
 PQA_API int pqa_set_motion_halo(pqa_ctx* ctx, const void* prev_ref_luma_host, int64_t row_stride);
 

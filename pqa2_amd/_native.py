@@ -23,7 +23,7 @@ PROF_KERNELS = 15
 # every symbol include/pqa_vmaf.h declares
 EXPORTS = [
     "pqa_version", "pqa_record_doubles", "pqa_config_init", "pqa_create", "pqa_destroy", "pqa_set_stream",
-    "pqa_submit", "pqa_submit_device", "pqa_set_motion_halo", "pqa_flush", "pqa_collect", "pqa_sync",
+    "pqa_submit", "pqa_submit_device", "pqa_submit_surfaces", "pqa_set_motion_halo", "pqa_flush", "pqa_collect", "pqa_sync",
     "pqa_cancel", "pqa_reset", "pqa_last_error", "pqa_luma_stats_device", "pqa_luma_stats", "pqa_profile_enable",
     "pqa_profile_read", "pqa_profile_kernel_name",
 ]
@@ -42,6 +42,15 @@ class PqaConfig(C.Structure):
 
 class PqaDeviceClip(C.Structure):
     _fields_ = [("plane", C.c_void_p * 3), ("row_pitch", C.c_int64 * 3), ("frame_pitch", C.c_int64 * 3)]
+
+
+SURFACE_NV12, SURFACE_P01X = 1, 2
+
+
+class PqaSurfaceClip(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("format", C.c_uint32), ("luma", C.c_void_p), ("chroma", C.c_void_p),
+                ("luma_row_pitch", C.c_int64), ("luma_frame_pitch", C.c_int64),
+                ("chroma_row_pitch", C.c_int64), ("chroma_frame_pitch", C.c_int64)]
 
 
 class PqaError(RuntimeError):
@@ -101,6 +110,8 @@ def load():
     lib.pqa_set_stream.argtypes = [vp, vp]
     lib.pqa_submit.argtypes = [vp, i64, C.POINTER(vp * 3), C.POINTER(i64 * 3), C.POINTER(vp * 3), C.POINTER(i64 * 3)]
     lib.pqa_submit_device.argtypes = [vp, i64, i32, C.POINTER(PqaDeviceClip), C.POINTER(PqaDeviceClip), vp, i64]
+    lib.pqa_submit_surfaces.argtypes = [vp, i64, i32, C.POINTER(PqaSurfaceClip), C.POINTER(PqaSurfaceClip),
+                                        C.POINTER(PqaSurfaceClip)]
     lib.pqa_set_motion_halo.argtypes = [vp, vp, i64]
     lib.pqa_flush.argtypes = [vp]
     lib.pqa_collect.argtypes = [vp, i64, i32, vp]

@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "ingest.h"
 #include "kernels.h"
 
 using namespace pqa;
@@ -213,6 +214,7 @@ struct pqa_ctx {
   size_t plane_off[2][3] = {};
   int64_t slot_row_pitch[3] = {};
   bool staging_ready = false;
+  uint8_t* surf_dev = nullptr;   // pqa_submit_surfaces: B slots of unpacked planes (device only, allocated on first use)
   std::unique_ptr<PackPool> pack_pool;
   bool pack_pool_tried = false;
   std::vector<PackTask> pack_tasks;
@@ -625,8 +627,9 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   return PQA_OK;
 }
 
-int ensure_staging(pqa_ctx* c) {
-  if (c->staging_ready) return PQA_OK;
+// One frame pair as the library lays it out itself (pinned staging, its device copy, unpacked decoder surfaces): ref
+// planes then dis planes, rows padded to 64 bytes, planes to 256.
+void slot_layout(pqa_ctx* c) {
   size_t off = 0;
   for (int side = 0; side < 2; ++side)
     for (int p = 0; p < c->n_planes; ++p) {
@@ -635,6 +638,11 @@ int ensure_staging(pqa_ctx* c) {
       off += round_up(c->slot_row_pitch[p] * c->ph[p], 256);
     }
   c->slot_bytes = off;
+}
+
+int ensure_staging(pqa_ctx* c) {
+  if (c->staging_ready) return PQA_OK;
+  slot_layout(c);
   const size_t half_bytes = c->slot_bytes * c->HB;
   bool reused = false;
   if (staging_cache_enabled()) {
@@ -974,6 +982,93 @@ int pqa_submit_device(pqa_ctx* c, int64_t first_index, int32_t n_frames, const p
       prev = (const uint8_t*)ref->plane[0] + (int64_t)(done - 1) * ref->frame_pitch[0];
       prev_pitch = ref->row_pitch[0];
     }
+    rc = process_batch(c, first_index + done, n, &r, &d, prev, prev_pitch);
+    if (rc != PQA_OK) return rc;
+    done += n;
+  }
+  return PQA_OK;
+}
+
+int pqa_submit_surfaces(pqa_ctx* c, int64_t first_index, int32_t n_frames, const pqa_surface_clip* ref,
+                        const pqa_surface_clip* dis, const pqa_surface_clip* prev_ref) {
+  if (!c) return PQA_EINVAL;
+  if (!ref || !dis || n_frames < 0 || first_index < 0) return fail(c, PQA_EINVAL, "bad argument");
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  if (n_frames > c->capacity)
+    return fail(c, PQA_ESTATE, "%d frames in one call exceed result_capacity %d (records would overwrite each other)",
+                n_frames, c->capacity);
+  const int bpc = (int)c->cfg.bit_depth;
+  const uint32_t want = bpc <= 8 ? (uint32_t)PQA_SURFACE_NV12 : (uint32_t)PQA_SURFACE_P01X;
+  const pqa_surface_clip* all[3] = {ref, dis, prev_ref};
+  for (int i = 0; i < 3; ++i) {
+    const pqa_surface_clip* s = all[i];
+    if (!s) continue;
+    if (s->struct_size != sizeof(pqa_surface_clip)) return fail(c, PQA_EINVAL, "pqa_surface_clip.struct_size mismatch");
+    if (s->format != want)
+      return fail(c, PQA_EINVAL, "surface format %u does not fit a %d-bit context (NV12 for 8 bit, P01X above)", s->format, bpc);
+    if (!s->luma || s->luma_row_pitch < (int64_t)c->pw[0] * c->esize || s->luma_row_pitch % c->esize)
+      return fail(c, PQA_EINVAL, "surface luma pointer / pitch");
+    if (i < 2 && c->n_planes == 3 &&
+        (!s->chroma || s->chroma_row_pitch < (int64_t)c->pw[1] * 2 * c->esize || s->chroma_row_pitch % c->esize))
+      return fail(c, PQA_EINVAL, "surface chroma pointer / pitch");
+  }
+  if (c->n_planes == 3 && (c->cfg.chroma_hshift != 1 || c->cfg.chroma_vshift != 1))
+    return fail(c, PQA_EINVAL, "decoder surfaces are 4:2:0: the context's chroma shifts must be 1, 1");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = flush_pending(c);
+  if (rc != PQA_OK) return rc;
+  if ((rc = check_slots_free(c, first_index, n_frames)) != PQA_OK) return rc;   // before anything is unpacked
+  const bool shift_luma = bpc > 8;
+  const int shift = 16 - bpc;
+  // Unpacked planes go to a device buffer of B slots.  One buffer is enough: unpack and scoring run on the same stream,
+  // so the next batch's unpack starts when this batch's kernels are done.
+  const bool stage = shift_luma || c->n_planes == 3;
+  if (stage && !c->surf_dev) {
+    slot_layout(c);
+    HIPCHK(c, hipMalloc((void**)&c->surf_dev, c->slot_bytes * (size_t)c->B));
+    c->allocs.push_back(c->surf_dev);
+  }
+  if (prev_ref && (c->cfg.features & PQA_FEAT_MOTION)) {
+    if (shift_luma) {   // the halo frame goes where a previous batch would have left it, shifted down
+      HIPCHK(c, launch_ingest_shift16(c->stream, prev_ref->luma, prev_ref->luma_row_pitch, 0, c->last_luma, c->last_luma_pitch,
+                                      0, c->pw[0], c->ph[0], shift, 1));
+      c->halo_armed = true;
+    }
+  }
+  for (int done = 0; done < n_frames;) {
+    if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+    const int n = n_frames - done < c->B ? n_frames - done : c->B;
+    pqa_device_clip r{}, d{};
+    const pqa_surface_clip* side[2] = {ref, dis};
+    pqa_device_clip* out[2] = {&r, &d};
+    for (int sd = 0; sd < 2; ++sd) {
+      const pqa_surface_clip* s = side[sd];
+      const uint8_t* luma = (const uint8_t*)s->luma + (int64_t)done * s->luma_frame_pitch;
+      if (shift_luma) {
+        uint8_t* dst = c->surf_dev + c->plane_off[sd][0];
+        HIPCHK(c, launch_ingest_shift16(c->stream, luma, s->luma_row_pitch, s->luma_frame_pitch, dst, c->slot_row_pitch[0],
+                                        (int64_t)c->slot_bytes, c->pw[0], c->ph[0], shift, n));
+        out[sd]->plane[0] = dst; out[sd]->row_pitch[0] = c->slot_row_pitch[0]; out[sd]->frame_pitch[0] = (int64_t)c->slot_bytes;
+      } else {   // NV12 luma: scored in place
+        out[sd]->plane[0] = luma; out[sd]->row_pitch[0] = s->luma_row_pitch; out[sd]->frame_pitch[0] = s->luma_frame_pitch;
+      }
+      if (c->n_planes == 3) {
+        const uint8_t* uv = (const uint8_t*)s->chroma + (int64_t)done * s->chroma_frame_pitch;
+        uint8_t* du = c->surf_dev + c->plane_off[sd][1];
+        uint8_t* dv = c->surf_dev + c->plane_off[sd][2];
+        if (c->slot_row_pitch[1] != c->slot_row_pitch[2]) return fail(c, PQA_EINVAL, "internal: U and V staging pitches differ");
+        HIPCHK(c, launch_ingest_deinterleave(c->stream, c->esize, uv, s->chroma_row_pitch, s->chroma_frame_pitch, du, dv,
+                                             c->slot_row_pitch[1], (int64_t)c->slot_bytes, c->pw[1], c->ph[1],
+                                             shift_luma ? shift : 0, n));
+        out[sd]->plane[1] = du; out[sd]->plane[2] = dv;
+        out[sd]->row_pitch[1] = out[sd]->row_pitch[2] = c->slot_row_pitch[1];
+        out[sd]->frame_pitch[1] = out[sd]->frame_pitch[2] = (int64_t)c->slot_bytes;
+      }
+    }
+    // the halo of the first batch: an NV12 luma plane is usable as it is; a shifted one was armed above
+    const void* prev = nullptr;
+    int64_t prev_pitch = 0;
+    if (done == 0 && prev_ref && !shift_luma) { prev = prev_ref->luma; prev_pitch = prev_ref->luma_row_pitch; }
     rc = process_batch(c, first_index + done, n, &r, &d, prev, prev_pitch);
     if (rc != PQA_OK) return rc;
     done += n;

@@ -101,6 +101,25 @@ class FeatureEngine:
         self._check(self.lib.pqa_submit_device(self._ctx, first_index, n_frames, C.byref(r), C.byref(d),
                                                prev_ref_luma_ptr or None, prev_row_pitch))
 
+    @staticmethod
+    def surface_clip(fmt: int, luma_ptr: int, luma_row_pitch: int, luma_frame_pitch: int, chroma_ptr: int = 0,
+                     chroma_row_pitch: int = 0, chroma_frame_pitch: int = 0) -> "N.PqaSurfaceClip":
+        """A clip of decoder surfaces in device memory (NV12 / P010 / P012; pitches in bytes)."""
+        s = N.PqaSurfaceClip()
+        s.struct_size = C.sizeof(N.PqaSurfaceClip)
+        s.format = fmt
+        s.luma, s.chroma = luma_ptr or None, chroma_ptr or None
+        s.luma_row_pitch, s.luma_frame_pitch = luma_row_pitch, luma_frame_pitch
+        s.chroma_row_pitch, s.chroma_frame_pitch = chroma_row_pitch, chroma_frame_pitch
+        return s
+
+    def submit_surfaces(self, first_index: int, n_frames: int, ref: "N.PqaSurfaceClip", dis: "N.PqaSurfaceClip",
+                        prev_ref: "N.PqaSurfaceClip | None" = None):
+        """Frames as a hardware decoder leaves them (pqa_submit_surfaces): NV12 luma is scored in place, interleaved
+        chroma is split and 16-bit samples are shifted down on the device."""
+        self._check(self.lib.pqa_submit_surfaces(self._ctx, first_index, n_frames, C.byref(ref), C.byref(dis),
+                                                 C.byref(prev_ref) if prev_ref is not None else None))
+
     def luma_stats_resident(self, luma_ptr: int, row_pitch: int, frame_pitch: int, n_frames: int,
                             threshold: int) -> np.ndarray:
         """[n,3] uint64 {sum, sum of squares, count(sample > threshold)} per frame of a clip in HBM."""
