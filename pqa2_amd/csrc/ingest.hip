@@ -37,8 +37,8 @@ __device__ __forceinline__ unsigned shr16x2(unsigned x, int s) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-// VEC: every source row starts 16-byte aligned (base and pitches multiples of 16); the destination is the library's
-// own staging (64-byte row pitch), so a full chunk may spill into the row's padding but never into the next row.
+// VEC: every source row starts 16-byte aligned (base and pitches multiples of 16) and so does every destination row (the
+// library's own slot layout: 64-byte row pitch).  Only chunks that lie completely inside the row take the 16-byte path.
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(kBlock) void ingest_kernel(const IngestArgs a) {
   const int chunk = blockIdx.x * kBlock + threadIdx.x;   // 8 output samples per chunk
