@@ -128,6 +128,15 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
   const T* __restrict__ dis = (const T*)a.dis + (int64_t)fr * a.frame_pitch_d;
   const int cx0 = tx * TW, cy0 = ty * TH;
   const int tid = threadIdx.x;
+  // A tile with no coefficient inside the accumulation window [left, right) x [top, bottom) (integer_adm.c crops 10 % on
+  // every side: a third of a frame's tiles) contributes zeros to every sum; all it owes is its piece of the approximation
+  // band the next scale reads (as in adm.hip).  Workgroup-uniform.
+  const bool outside = !(cx0 < a.right && cx0 + TW > a.left && cy0 < a.bottom && cy0 + TH > a.top);
+  long long* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * (GH * 6);
+  if (outside) {
+    if (tid < GH * 6) out[tid] = 0;
+    if (!a.ll_ref) return;   // last scale: nothing else to produce
+  }
   const unsigned pitch_r = (unsigned)a.row_pitch_r, pitch_d = (unsigned)a.row_pitch_d;
   const rsrc_t rsrc_r = make_rsrc(ref, (unsigned)a.h * pitch_r * (unsigned)sizeof(T));
   const rsrc_t rsrc_d = make_rsrc(dis, (unsigned)a.h * pitch_d * (unsigned)sizeof(T));
@@ -156,9 +165,11 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
             ld += kLo[k] * d[2 * o + k]; hd += kHi[k] * d[2 * o + k];
           }
           V[0][row][col] = (lr + a.add_vp) >> a.shift_vp;
-          V[1][row][col] = (hr + a.add_vp) >> a.shift_vp;
           V[2][row][col] = (ld + a.add_vp) >> a.shift_vp;
-          V[3][row][col] = (hd + a.add_vp) >> a.shift_vp;
+          if (!outside) {
+            V[1][row][col] = (hr + a.add_vp) >> a.shift_vp;
+            V[3][row][col] = (hd + a.add_vp) >> a.shift_vp;
+          }
         } else {
           long long lr = 0, hr = 0, ld = 0, hd = 0;
 #pragma unroll
@@ -167,9 +178,11 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
             ld += (long long)kLo[k] * d[2 * o + k]; hd += (long long)kHi[k] * d[2 * o + k];
           }
           V[0][row][col] = (int)((lr + a.add_vp) >> a.shift_vp);
-          V[1][row][col] = (int)((hr + a.add_vp) >> a.shift_vp);
           V[2][row][col] = (int)((ld + a.add_vp) >> a.shift_vp);
-          V[3][row][col] = (int)((hd + a.add_vp) >> a.shift_vp);
+          if (!outside) {
+            V[1][row][col] = (int)((hr + a.add_vp) >> a.shift_vp);
+            V[3][row][col] = (int)((hd + a.add_vp) >> a.shift_vp);
+          }
         }
       }
     }
@@ -193,6 +206,32 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
   for (int k = 0; k < 4; ++k) {
     const int lr = wave + 4 * k;
     const int cy = cy0 - 1 + lr;
+    if (outside) {   // approximation band only: the low vertical bands through the low-pass taps
+      const bool row_valid_o = cy >= 0 && cy < a.oh;
+      if (col_inner && lr >= 1 && lr <= TH && row_valid_o) {
+        int ll[2];
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+          const int2* p = reinterpret_cast<const int2*>(&V[2 * im][lr][2 * lcxs]);
+          const int2 v01 = p[0], v23 = p[1];
+          const int sv[4] = {v01.x, v01.y, v23.x, v23.y};
+          if (!WIDE) {
+            int ba = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ba += kLo[t] * sv[t];
+            ll[im] = (short)((ba + a.add_hp) >> a.shift_hp);
+          } else {
+            long long ba = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ba += (long long)kLo[t] * sv[t];
+            ll[im] = (int)((ba + a.add_hp) >> a.shift_hp);
+          }
+        }
+        a.ll_ref[(int64_t)fr * a.ll_frame_pitch_r + (int64_t)cy * a.ll_row_pitch_r + cx] = ll[0];
+        a.ll_dis[(int64_t)fr * a.ll_frame_pitch_d + (int64_t)cy * a.ll_row_pitch_d + cx] = ll[1];
+      }
+      continue;
+    }
     int s[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -289,12 +328,12 @@ __global__ __launch_bounds__(kBlock, 2) void adm_fixed_kernel(const AfxArgs a) {
       den[k][t] = (long long)val;
     }
   }
+  if (outside) return;   // (its partials were cleared at the top)
   __syncthreads();
 
   // ---- phase 3: contrast masking; per-row sums ------------------------------------------------------
   const int lx0 = have ? min(max(mirror1(cx - 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
   const int lx2 = have ? min(max(mirror1(cx + 1, a.ow) - (cx0 - 1), 0), GW - 1) : 0;
-  long long* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * (GH * 6);
   long long sums[24];  // index k * 6 + {num h,v,d, den h,v,d}
 #pragma unroll
   for (int k = 0; k < 4; ++k) {

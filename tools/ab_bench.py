@@ -15,6 +15,7 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--features", type=int, default=7, help="PQA_FEAT_* mask: 1 VIF, 2 ADM, 4 motion (isolate one chain)")
 ap.add_argument("--bits", type=int, default=8)
+ap.add_argument("--fixed", type=int, default=0, help="pqa_config.fixed_point mask")
 a = ap.parse_args()
 w, h = map(int, a.size.split("x"))
 clip = synth_torch.make_clip_cuda(w, h, a.frames, a.bits)
@@ -29,7 +30,7 @@ def bind(path):
     lib.pqa_destroy.argtypes = [vp]; lib.pqa_destroy.restype = None
     lib.pqa_submit_device.argtypes = [vp, i64, i32, C.POINTER(N.PqaDeviceClip), C.POINTER(N.PqaDeviceClip), vp, i64]
     lib.pqa_sync.argtypes = [vp]; lib.pqa_reset.argtypes = [vp]
-    cfg = N.PqaConfig(); lib.pqa_config_init(C.byref(cfg), w, h); cfg.max_batch = a.batch; cfg.features = a.features; cfg.bit_depth = a.bits
+    cfg = N.PqaConfig(); lib.pqa_config_init(C.byref(cfg), w, h); cfg.max_batch = a.batch; cfg.features = a.features; cfg.bit_depth = a.bits; cfg.fixed_point = a.fixed
     ctx = vp(); assert lib.pqa_create(C.byref(cfg), C.byref(ctx)) == 0
     return lib, ctx
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Are two builds of libpqa_vmaf.so BIT-identical on the same clips?  (for changes that must not move a single result:
 work skipped because its contribution is zero by definition, address arithmetic, launch shape)
-usage: ab_equal.py A.so B.so [--features 7]      exit code 1 when any record differs."""
+usage: ab_equal.py A.so B.so [--features 7] [--fixed 7]      exit code 1 when any record differs."""
 import argparse, ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +11,7 @@ from pqa2_amd import _native as N, synth_torch
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs=2)
 ap.add_argument("--features", type=int, default=7)
+ap.add_argument("--fixed", type=int, default=0, help="pqa_config.fixed_point mask (7 = every extractor in fixed point)")
 a = ap.parse_args()
 CASES = [(3840, 2160, 8, 6), (1920, 1080, 8, 6), (1039, 913, 8, 4), (200, 120, 8, 4), (64, 48, 8, 3), (3840, 2160, 10, 4),
          (1280, 720, 10, 4), (720, 486, 12, 3)]
@@ -25,7 +26,7 @@ def run(path, w, h, bits, n, R, D):
     lib.pqa_submit_device.argtypes = [vp, i64, i32, C.POINTER(N.PqaDeviceClip), C.POINTER(N.PqaDeviceClip), vp, i64]
     lib.pqa_collect.argtypes = [vp, i64, i32, C.POINTER(C.c_double)]
     cfg = N.PqaConfig(); lib.pqa_config_init(C.byref(cfg), w, h)
-    cfg.max_batch = 4; cfg.features = a.features; cfg.bit_depth = bits; cfg.n_planes = 1
+    cfg.max_batch = 4; cfg.features = a.features; cfg.bit_depth = bits; cfg.n_planes = 1; cfg.fixed_point = a.fixed
     ctx = vp(); assert lib.pqa_create(C.byref(cfg), C.byref(ctx)) == 0
     r, d = N.PqaDeviceClip(), N.PqaDeviceClip()
     es = 1 if bits <= 8 else 2
