@@ -575,6 +575,31 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
       // the border rule per lane (same folds as the VALU kernel): two loads per row, rows mirrored one by one
       const unsigned gx0 = (unsigned)mirror_fold(x0 - (N / 2) + col0, a.w, a.fold_w) * ES;
       const unsigned gx1 = (unsigned)mirror_fold(x0 - (N / 2) + col0 + 1, a.w, a.fold_w) * ES;
+      // most edge pairs sit in the first / last tile COLUMN with all 32 rows inside the image (270 of 298 at 2160p): their
+      // rows need no fold -- a scalar offset per row as in the interior kernel, only the two columns are per-lane
+      const bool rows_in = y0 - (N / 2) >= 0 && y0 - (N / 2) + 32 <= a.h;   // workgroup-uniform
+      if (rows_in) {
+        const unsigned gyb = (unsigned)(y0 - (N / 2) + 8 * g);
+        const unsigned br0 = gyb * pitch_r + gx0, br1 = gyb * pitch_r + gx1, bd0 = gyb * pitch_d + gx0, bd1 = gyb * pitch_d + gx1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (W16) {
+            const unsigned r0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, br0, (unsigned)j * pitch_r, 0);
+            const unsigned r1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, br1, (unsigned)j * pitch_r, 0);
+            const unsigned d0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, bd0, (unsigned)j * pitch_d, 0);
+            const unsigned d1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, bd1, (unsigned)j * pitch_d, 0);
+            rr_[j] = r0 | (r1 << 16);
+            dr_[j] = d0 | (d1 << 16);
+          } else {
+            const unsigned r0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, br0, (unsigned)j * pitch_r, 0) & 0xffu;
+            const unsigned r1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, br1, (unsigned)j * pitch_r, 0) & 0xffu;
+            const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, bd0, (unsigned)j * pitch_d, 0) & 0xffu;
+            const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, bd1, (unsigned)j * pitch_d, 0) & 0xffu;
+            rr_[j] = r0 | (r1 << 8);
+            dr_[j] = d0 | (d1 << 8);
+          }
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned gy = (unsigned)mirror_fold(y0 - (N / 2) + 8 * g + j, a.h, a.fold_h);
@@ -593,6 +618,7 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
           rr_[j] = r0 | (r1 << 8);
           dr_[j] = d0 | (d1 << 8);
         }
+      }
       }
     }
     unsigned cm_[8], pm_[8];   // motion: current / previous reference rows (two columns each, as rr_)
