@@ -57,6 +57,14 @@ def test_surfaces_give_the_planar_records(w, h, bpc, pad):
         eng.submit_surfaces(2, n - 2, mk(RL, RC, 2), mk(DL, DC, 2), prev_ref=mk(RL, RC, 1))
         shard = eng.collect(2, n - 2)
     assert np.array_equal(shard.view(np.uint64), planar[2:].view(np.uint64))
+    # one context, three ways in: host planes, then surfaces (motion continues across the switch), then resident planes
+    with FeatureEngine(w, h, **kw) as eng:
+        for i in range(2):
+            eng.submit(i, refs[i], diss[i])
+        eng.submit_surfaces(2, 2, mk(RL, RC, 2), mk(DL, DC, 2))
+        eng.submit(4, refs[4], diss[4])
+        mixed = eng.collect(0, n)
+    assert np.array_equal(mixed.view(np.uint64), planar.view(np.uint64))
     # luma-only context (VMAF): an NV12 luma plane is scored in place, no chroma pointer needed
     with FeatureEngine(w, h, bit_depth=bpc, max_batch=4) as eng:
         s = lambda L: FeatureEngine.surface_clip(fmt, L.data_ptr(), lp * es, h * lp * es)
@@ -84,6 +92,9 @@ def test_surface_argument_errors():
         with pytest.raises(N.PqaError):
             eng.submit_surfaces(0, 1, ok, nochroma)
         eng.submit_surfaces(0, 1, ok, ok)          # and the context is still usable
+        with pytest.raises(N.PqaError) as e:       # frame 0's record has not been collected: a frame that maps to its
+            eng.submit_surfaces(16384, 1, ok, ok)  # ring slot (index + result_capacity) must not overwrite it
+        assert e.value.code == N.PQA_ESTATE
         assert np.all(np.isfinite(eng.collect(0, 1)))
     with FeatureEngine(w, h, n_planes=3, chroma_shift=(0, 0), features=N.FEAT_ALL) as eng:   # 4:4:4 context
         with pytest.raises(N.PqaError):
