@@ -601,24 +601,24 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
         }
       } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned gy = (unsigned)mirror_fold(y0 - (N / 2) + 8 * g + j, a.h, a.fold_h);
-        if (W16) {
-          const unsigned r0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, gy * pitch_r + gx0, 0, 0);
-          const unsigned r1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, gy * pitch_r + gx1, 0, 0);
-          const unsigned d0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, gy * pitch_d + gx0, 0, 0);
-          const unsigned d1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, gy * pitch_d + gx1, 0, 0);
-          rr_[j] = r0 | (r1 << 16);
-          dr_[j] = d0 | (d1 << 16);
-        } else {
-          const unsigned r0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx0, 0, 0) & 0xffu;
-          const unsigned r1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx1, 0, 0) & 0xffu;
-          const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx0, 0, 0) & 0xffu;
-          const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx1, 0, 0) & 0xffu;
-          rr_[j] = r0 | (r1 << 8);
-          dr_[j] = d0 | (d1 << 8);
+        for (int j = 0; j < 8; ++j) {
+          const unsigned gy = (unsigned)mirror_fold(y0 - (N / 2) + 8 * g + j, a.h, a.fold_h);
+          if (W16) {
+            const unsigned r0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, gy * pitch_r + gx0, 0, 0);
+            const unsigned r1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, gy * pitch_r + gx1, 0, 0);
+            const unsigned d0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, gy * pitch_d + gx0, 0, 0);
+            const unsigned d1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, gy * pitch_d + gx1, 0, 0);
+            rr_[j] = r0 | (r1 << 16);
+            dr_[j] = d0 | (d1 << 16);
+          } else {
+            const unsigned r0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx0, 0, 0) & 0xffu;
+            const unsigned r1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx1, 0, 0) & 0xffu;
+            const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx0, 0, 0) & 0xffu;
+            const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, gy * pitch_d + gx1, 0, 0) & 0xffu;
+            rr_[j] = r0 | (r1 << 8);
+            dr_[j] = d0 | (d1 << 8);
+          }
         }
-      }
       }
     }
     unsigned cm_[8], pm_[8];   // motion: current / previous reference rows (two columns each, as rr_)
