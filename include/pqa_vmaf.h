@@ -141,7 +141,10 @@ PQA_API int pqa_set_stream(pqa_ctx* ctx, void* hip_stream);
 PQA_API int pqa_submit(pqa_ctx* ctx, int64_t frame_index, const void* const ref_planes[3], const int64_t ref_strides[3],
                const void* const dis_planes[3], const int64_t dis_strides[3]);
 
-/* Submit n_frames consecutive frame pairs that are ALREADY in device memory (no copies).
+/* Submit n_frames consecutive frame pairs that are ALREADY in device memory (no copies).  "Already" includes ordering:
+ * the context's kernels run on its own stream (or the one given to pqa_set_stream), so whatever produced the frames must be
+ * complete -- or on that same stream -- before this call; the same holds for pqa_submit_surfaces and
+ * pqa_luma_stats_device.
  * prev_ref_luma (nullable, device pointer, prev_row_pitch bytes) is the reference luma of frame
  * first_index-1 -- the one-frame halo a frame-sharded rank needs for motion.  When NULL the context
  * continues from the last frame it saw if that was first_index-1, else motion(first_index) = 0. */

@@ -86,12 +86,14 @@ def test_config_2160p_10bit_neg_psnr_ssim_all_planes(oracle32):
         pair = eng.collect(0, n)
         static = [t[:1].expand(n, *t.shape[1:]).contiguous() for t in clip["ref"]]
         sp = [t.data_ptr() for t in static]
+        torch.cuda.synchronize()   # the context runs on its own stream: torch's copies must have landed
         eng.reset()
         eng.submit_resident(0, n, sp, sp, rpitch, fpitch)                      # static
         stat = eng.collect(0, n)
         c = 5
         lo = [t.to(torch.int32).clamp(0, 1023 - c).to(torch.int16) for t in clip["ref"]]
         hi = [(t.to(torch.int32) + c).to(torch.int16) for t in lo]
+        torch.cuda.synchronize()
         eng.reset()
         eng.submit_resident(0, n, [t.data_ptr() for t in lo], [t.data_ptr() for t in hi], rpitch, fpitch)
         off = eng.collect(0, n)
@@ -183,6 +185,7 @@ def test_overwriting_an_uncollected_record_is_estate():
     # device-resident submit: the same rule, checked per batch before anything is launched
     R = torch.from_numpy(np.stack([r[0] for r in refs])).cuda()
     D = torch.from_numpy(np.stack([d[0] for d in diss])).cuda()
+    torch.cuda.synchronize()
     with FeatureEngine(w, h, max_batch=2, result_capacity=4) as eng:
         eng.submit_resident(0, 4, [R.data_ptr()], [D.data_ptr()], [w], [w * h])
         with pytest.raises(N.PqaError) as e:

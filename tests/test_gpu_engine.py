@@ -76,12 +76,14 @@ def test_full_size_properties(w, h):
         pair = eng.collect(0, 3)
         Rs = R[:1].expand(3, h, w).contiguous()
         eng.reset()
+        torch.cuda.synchronize()   # the context has its own stream: torch's kernels must be done
         eng.submit_resident(0, 3, [Rs.data_ptr()], [Rs.data_ptr()], [w], [w * h])        # static
         static = eng.collect(0, 3)
         c = 3
         Ro = (R.to(torch.int16).clamp(0, 255 - c) + c).to(torch.uint8)
         Rc = R.to(torch.int16).clamp(0, 255 - c).to(torch.uint8)
         eng.reset()
+        torch.cuda.synchronize()
         eng.submit_resident(0, 3, [Rc.data_ptr()], [Ro.data_ptr()], [w], [w * h])        # constant offset
         off = eng.collect(0, 3)
     # vif: flat regions take the low-variance branch (num = 1 - sigma2^2 * 4/255^2, den = 1), so identical
