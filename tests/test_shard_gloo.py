@@ -41,7 +41,7 @@ def _worker(rank, world, port, rp, dp, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_equals_single_process(tmp_path, world):
     from pqa2_amd import synth, yuvio
     from pqa2_amd.pipeline import score_files
