@@ -246,8 +246,8 @@ def _strip_fps(path):
     return json.dumps(d, sort_keys=True)
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
-def test_torchrun_ranks_share_the_gpu_and_match_single_process(tmp_path, ranks):
+@pytest.mark.parametrize("ranks,n", [(2, 11), (3, 11), (4, 3)])
+def test_torchrun_ranks_share_the_gpu_and_match_single_process(tmp_path, ranks, n):
     """python -m torch.distributed.run --nproc-per-node N -m pqa2_amd.score: N fresh processes, each with its own
     pqa_ctx on the HIP engine (frame shard + one-frame motion halo through pqa_set_motion_halo), records all-gathered
     (gloo here: the ranks share this box's single GPU; RCCL needs one GPU per rank), rank 0 writes JSON + stats files.
@@ -255,7 +255,8 @@ def test_torchrun_ranks_share_the_gpu_and_match_single_process(tmp_path, ranks):
     import os
     import subprocess
     import sys
-    w, h, n = 320, 180, 11        # 11 frames over 2 / 3 ranks: uneven shards, seams at odd positions
+    w, h = 320, 180               # 11 frames over 2 / 3 ranks: uneven shards, seams at odd positions; 3 frames over 4
+                                  # ranks: one rank's shard is empty
     rp, dp = _write_pair(tmp_path, w, h, n)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
