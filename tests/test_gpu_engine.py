@@ -194,6 +194,11 @@ def test_ragged_clip_lengths_use_the_shorter(tmp_path):
     yuvio.write_y4m(dp, diss[:3], info)
     res = score_files(rp, dp, "vmaf_v0.6.1")
     assert res["records"].shape[0] == 3 and list(res["frame_indices"]) == [0, 1, 2]
+    yuvio.write_y4m(dp, diss[:1], info)          # a single frame: no predecessor, no successor
+    one = score_files(rp, dp, "vmaf_v0.6.1")
+    assert one["records"].shape[0] == 1 and one["records"][0, 16] == 0.0
+    assert np.all(np.isfinite(one["records"][:, :17]))
+    assert np.array_equal(one["records"][0, :16], res["records"][0, :16])   # frame 0 scores as it does inside a clip
     yuvio.write_y4m(dp, [], info)
     with pytest.raises(ValueError):
         score_files(rp, dp, "vmaf_v0.6.1")
