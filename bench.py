@@ -35,6 +35,15 @@ WORKLOADS = {
     "2160p10": (3840, 2160, 10, "vmaf_v0.6.1neg", True),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+_T0 = time.perf_counter()
+_STAGES = os.environ.get("PQA_BENCH_STAGES", "") == "1"
+
+
+def _stage(msg: str):
+    """Flushed progress marker on stderr (PQA_BENCH_STAGES=1 / --stages): when a profiler pass stalls, the last marker
+    says where (tools/profile_round.sh keeps every pass's stderr)."""
+    if _STAGES:
+        print(f"[bench +{time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -60,8 +69,12 @@ def main():
     ap.add_argument("--fixed-point", type=int, default=0,
                     help="PQA_FIXED_* mask (1 VIF, 2 motion): measure libvmaf's fixed-point arithmetic instead of the "
                          "default f32 path")
+    ap.add_argument("--stages", action="store_true", help="flushed stage markers on stderr (also PQA_BENCH_STAGES=1)")
     args = ap.parse_args()
+    global _STAGES
+    _STAGES = _STAGES or args.stages
 
+    _stage("importing torch")
     import torch
     import torch.distributed as dist
     from pqa2_amd import _native as N
@@ -102,7 +115,9 @@ def main():
 
     # ---- synthetic clip straight into HBM (this rank's chunk + one halo frame in front) ----------
     halo = 1 if a > 0 else 0
-    clip = synth_torch.make_clip_cuda(w, h, F + halo, bpc, device=dev, chroma=side, t0=a - halo)
+    _stage(f"device {local_rank} selected; generating the synthetic clip ({F + (1 if a > 0 else 0)} frames {w}x{h} {bpc}-bit, chroma={side})")
+    clip = synth_torch.make_clip_cuda(w, h, F + halo, bpc, device=dev, chroma=side, t0=a - halo,
+                                      progress=_stage if _STAGES else None)
     es = 1 if bpc <= 8 else 2
     ref_t, dis_t = clip["ref"], clip["dis"]
     ref_ptrs = [t[halo:].data_ptr() for t in ref_t]
@@ -111,6 +126,7 @@ def main():
     frame_pitch = [t.shape[1] * t.shape[2] * es for t in ref_t]
     halo_ptr = ref_t[0][0].data_ptr() if halo else 0
     torch.cuda.synchronize()
+    _stage("clip generated and synchronised; creating the context")
 
     eng = FeatureEngine(w, h, bit_depth=bpc, n_planes=n_planes, features=feats, device=local_rank,
                         max_batch=args.batch, result_capacity=max(F, 1024),
@@ -119,6 +135,7 @@ def main():
                         fixed_point=args.fixed_point)
     prefix = "integer_" if model.is_integer else ""
     result = {}
+    _stage(f"context created (batch {args.batch})")
 
     def step():
         eng.reset()
@@ -158,23 +175,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        _stage(f"warm-up step {i + 1}/{args.warmup} done")
     if not args.no_events:
         eng.profile_enable([0])       # HIP events around the dominant kernel only (vif_stat_s0) while timing
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        _stage(f"timed step {i + 1}/{args.steps} submitted and collected")
     barrier()
     elapsed = time.perf_counter() - t0
+    _stage("timed region closed")
     prof = eng.profile_read() if not args.no_events else {}
+    _stage("kernel events read")
     breakdown = {}
     if not args.no_events:
         eng.profile_enable(True)      # one extra, untimed pass with every kernel timed, for the breakdown
         step()
         breakdown = eng.profile_read()
         eng.profile_enable(False)
+        _stage("breakdown pass done")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev if gather_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -337,12 +359,20 @@ def _bookend_leg():
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the sources of the dominant kernel: counters measured for another version of it are stale."""
+    """sha256 over the sources of the dominant kernel (VIF scale 0): counters measured for another version of it are stale.
+    Covers the VIF kernel files, the shared device helpers and the VIF section of kernels.h (tile geometry, launcher
+    contracts) -- not the declarations of unrelated kernels in that header."""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("vif.hip", "pqa_device.h", "kernels.h"):   # both scale-0 kernels live in vif.hip
-        with open(os.path.join(ROOT, "pqa2_amd", "csrc", f), "rb") as fh:
-            hsh.update(fh.read())
+    d = os.path.join(ROOT, "pqa2_amd", "csrc")
+    for f in ("vif.hip", "vif_march.hip", "pqa_device.h"):   # the scale-0 kernels live in vif.hip / vif_march.hip
+        if os.path.exists(os.path.join(d, f)):
+            with open(os.path.join(d, f), "rb") as fh:
+                hsh.update(fh.read())
+    with open(os.path.join(d, "kernels.h"), "rb") as fh:
+        k = fh.read()
+    a, b = k.find(b"// ---- VIF"), k.find(b"// ---- ADM")
+    hsh.update(k[a:b] if 0 <= a < b else k)
     return hsh.hexdigest()[:16]
 
 

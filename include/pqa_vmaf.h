@@ -218,6 +218,15 @@ PQA_API int pqa_luma_stats_device(pqa_ctx* ctx, const void* luma, int64_t row_pi
 PQA_API int pqa_luma_stats(pqa_ctx* ctx, const void* const* luma_frames, int64_t row_stride, int32_t n_frames,
                            uint32_t threshold, uint64_t* out);
 
+/* What "gray" means to the two luma-statistics calls above.  PQA_GRAY_LUMA (default): the luma samples as they are.
+ * PQA_GRAY_BT601_FULL: gray = clamp(round((Y - 16 s) * 255 / (219 s)), 0, 255), s = 2^(bit_depth - 8) -- what the
+ * reference's cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) sees for a limited-range clip (cv2.VideoCapture has expanded it to
+ * full-range BGR; with BT.601 on both legs the chroma terms cancel).  The statistics are then those of that 8-bit gray for
+ * every bit depth, and `threshold` is in its units: the absolute constants of the reference's rules (180 / 200 / 220 / 230 /
+ * 240, app/bookend_alignment.py:818-852, app/reference_analyzer.py:134) mean what they mean there. */
+enum { PQA_GRAY_LUMA = 0, PQA_GRAY_BT601_FULL = 1 };
+PQA_API int pqa_set_luma_gray(pqa_ctx* ctx, uint32_t mode);
+
 /* Measurement hooks (bench.py): HIP-event timing of individual kernels on the context's stream.
  * kernel ids: 0..3 vif_stat scale s (each also produces the next scale's planes), 4..6 reserved,
  * 7..10 adm scale s,

@@ -19,12 +19,14 @@ FIXED_VIF, FIXED_MOTION, FIXED_ADM, FIXED_ALL = 1, 2, 4, 7   # pqa_config.fixed_
 REC_VIF_NUM, REC_VIF_DEN, REC_ADM_NUM, REC_ADM_DEN, REC_MOTION, REC_SSIM, REC_SSE = 0, 4, 8, 12, 16, 17, 20
 RECORD_DOUBLES = 24
 PROF_KERNELS = 15
+GRAY_LUMA, GRAY_BT601_FULL = 0, 1   # pqa_set_luma_gray
 
 # every symbol include/pqa_vmaf.h declares
 EXPORTS = [
     "pqa_version", "pqa_record_doubles", "pqa_config_init", "pqa_create", "pqa_destroy", "pqa_set_stream",
     "pqa_submit", "pqa_submit_device", "pqa_submit_surfaces", "pqa_set_motion_halo", "pqa_flush", "pqa_collect", "pqa_sync",
-    "pqa_cancel", "pqa_reset", "pqa_last_error", "pqa_luma_stats_device", "pqa_luma_stats", "pqa_profile_enable",
+    "pqa_cancel", "pqa_reset", "pqa_last_error", "pqa_luma_stats_device", "pqa_luma_stats", "pqa_set_luma_gray",
+    "pqa_profile_enable",
     "pqa_profile_read", "pqa_profile_kernel_name",
 ]
 
@@ -119,6 +121,7 @@ def load():
     lib.pqa_cancel.argtypes = [vp]
     lib.pqa_luma_stats_device.argtypes = [vp, vp, i64, i64, i32, C.c_uint32, vp]
     lib.pqa_luma_stats.argtypes = [vp, C.POINTER(vp), i64, i32, C.c_uint32, vp]
+    lib.pqa_set_luma_gray.argtypes = [vp, C.c_uint32]
     lib.pqa_reset.argtypes = [vp]
     lib.pqa_last_error.argtypes = [vp]
     lib.pqa_last_error.restype = C.c_char_p

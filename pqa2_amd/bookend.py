@@ -5,7 +5,18 @@ cv2/numpy: `np.mean(gray)`, `np.std(gray)`, `np.sum(gray > threshold) / gray.siz
 (app/bookend_alignment.py:796-800, 902-913, 998-1020) and a "first 30 frames >= 85 % above 200" check
 (app/reference_analyzer.py:112-151).  Here the three reductions come from one streaming HIP kernel
 (`pqa_luma_stats_device`: sum, sum of squares, count above threshold -- exact integers) and the
-reference's decision rules are applied to them on the host.  Gray is taken to be the luma plane.
+reference's decision rules are applied to them on the host.
+
+What "gray" is (`gray=` of detect()).  The reference's gray is cv2.cvtColor(frame, COLOR_BGR2GRAY) of a frame that
+cv2.VideoCapture has already converted to full-range BGR: for a limited-range (TV) clip, Y = 235 arrives as 255 and
+Y = 190 as about 203, and the absolute constants of the rules (180 / 200 / 220 / 230 / 240) are in those units.
+  "bt601_full": gray = clamp(round((Y - 16 s) * 255 / (219 s)), 0, 255), s = 2^(bpc - 8) -- the expansion, applied PER
+                SAMPLE inside the reduction kernel (pqa_set_luma_gray), so clipping and rounding are the per-pixel ones
+                and the statistics are exact integers of the 8-bit gray;
+  "luma":       the luma samples as they are (scaled to 8-bit units) -- right for full-range clips;
+  "auto":       "luma" when the container says full range (Y4M XCOLORRANGE=FULL), else "bt601_full".
+Still parity-unpinned against cv2 itself (absent here): swscale's and cvtColor's own fixed-point roundings can move a
+gray value by one step; BT.601 on both legs is what makes the chroma terms cancel (swscale's default for untagged input).
 """
 from __future__ import annotations
 
@@ -48,20 +59,44 @@ def starts_with_bookend(white_ratio_at_200, max_frames: int = 30) -> bool:
 
 
 # ---- the detector: coarse scan -> regions -> frame-accurate scan (app/bookend_alignment.py:755-1133) -----------------
-def numpy_stats_fn(reader):
+def expand_bt601_full(y: np.ndarray, bit_depth: int) -> np.ndarray:
+    """Limited-range luma samples -> the 8-bit full-range gray of the module docstring, in exact integer arithmetic
+    (floor(x + 0.5) rounding, saturated to 0..255): what csrc/luma_stats.hip applies per sample."""
+    s = 1 << (bit_depth - 8)
+    v = (y.astype(np.int64) - 16 * s) * 510 + 219 * s
+    return np.clip(np.floor_divide(v, 438 * s), 0, 255).astype(np.uint64)
+
+
+def resolve_gray(gray: str, info) -> str:
+    if gray not in ("auto", "luma", "bt601_full"):
+        raise ValueError(f"gray must be 'auto', 'luma' or 'bt601_full', not {gray!r}")
+    if gray == "auto":
+        return "luma" if getattr(info, "color_range", None) == "full" else "bt601_full"
+    return gray
+
+
+def numpy_stats_fn(reader, gray: str = "luma"):
     """CPU stand-in for the GPU reduction, for tests: the same three exact integers from numpy."""
+    bpc = reader.info.bit_depth
+    mode = resolve_gray(gray, reader.info)
+
     def fn(indices, threshold):
         out = np.zeros((len(indices), 3), np.uint64)
         for k, i in enumerate(indices):
-            y = np.asarray(reader.frame(int(i))[0]).astype(np.uint64)
+            y = np.asarray(reader.frame(int(i))[0])
+            y = expand_bt601_full(y, bpc) if mode == "bt601_full" else y.astype(np.uint64)
             out[k] = (y.sum(), (y * y).sum(), (y > np.uint64(threshold)).sum())
         return out
     return fn
 
 
-def engine_stats_fn(reader, engine, chunk: int = 64):
+def engine_stats_fn(reader, engine, chunk: int = 64, gray: str = "luma"):
     """Frames of `reader` -> FeatureEngine.luma_stats (pqa_luma_stats: pack, upload, one streaming HIP reduction)."""
+    from . import _native as N
+    mode = N.GRAY_BT601_FULL if resolve_gray(gray, reader.info) == "bt601_full" else N.GRAY_LUMA
+
     def fn(indices, threshold):
+        engine.set_luma_gray(mode)
         parts = []
         for a in range(0, len(indices), chunk):
             frames = [reader.frame(int(i))[0] for i in indices[a:a + chunk]]
@@ -71,17 +106,20 @@ def engine_stats_fn(reader, engine, chunk: int = 64):
 
 
 def detect(reader, engine=None, *, frame_sampling_rate: float = 5, adaptive_brightness: bool = True,
-           white_threshold: float = 230, fallback_to_full_video: bool = True, stats_fn=None):
+           white_threshold: float = 230, fallback_to_full_video: bool = True, stats_fn=None, gray: str = "auto"):
     """White bookend sections of a clip, the reference's `_detect_white_bookends` (app/bookend_alignment.py:755-1133)
     on exact GPU reductions: returns the list of dicts {start_frame, end_frame, start_time, end_time, frame_count,
     brightness, std_dev[, is_fallback]} sorted by start_frame (the caller pairs first/last like the reference does).
 
     `reader`: a pqa2_amd.yuvio reader (len, .frame(i) -> planes, .info).  `engine`: a FeatureEngine of the clip's
     geometry (its pqa_luma_stats does the reductions); or pass `stats_fn(indices, int_threshold) -> [n,3] uint64`.
-    Gray is the luma plane, in 8-bit units (deeper samples are scaled down by 2^(bpc-8), the count threshold up).
-    Differences from the reference, none of which changes a decision: the per-frame (mean, std) of the coarse pass
-    are computed once and reused for all three thresholds (the reference re-decodes the clip per threshold); frames are
-    fetched by index instead of cv2 seeks."""
+    `gray`: "auto" | "luma" | "bt601_full" (module docstring).  With a caller-supplied `stats_fn` the function must
+    already deliver statistics of that gray (numpy_stats_fn(reader, gray) / engine_stats_fn(reader, engine, gray=...)).
+    In "luma" mode deeper samples are scaled to 8-bit units (the count threshold up); in "bt601_full" mode the kernel's
+    gray is 8-bit for every depth.
+    Structural differences from the reference that change no decision: the per-frame (mean, std) of the coarse pass are
+    computed once and reused for all three thresholds (the reference re-decodes the clip per threshold); frames are
+    fetched by index instead of cv2 seeks.  Against cv2's own gray the result is parity-unpinned (module docstring)."""
     info = reader.info
     fps = float(info.fps)
     frame_count = len(reader)
@@ -89,11 +127,12 @@ def detect(reader, engine=None, *, frame_sampling_rate: float = 5, adaptive_brig
         return None
     duration = frame_count / fps
     n_pixels = info.width * info.height
-    scale = float(1 << (info.bit_depth - 8))
+    mode = resolve_gray(gray, info)
+    scale = 1.0 if mode == "bt601_full" else float(1 << (info.bit_depth - 8))
     if stats_fn is None:
         if engine is None:
             raise ValueError("detect() needs a FeatureEngine (the reductions run on the GPU) or a stats_fn")
-        stats_fn = engine_stats_fn(reader, engine)
+        stats_fn = engine_stats_fn(reader, engine, gray=mode)
 
     def brightness(indices, threshold8=255.0):
         thr = int(np.floor(max(0.0, float(threshold8)) * scale))   # gray > t  <=>  integer sample > floor(t * scale)

@@ -133,8 +133,12 @@ hipError_t launch_ssim(hipStream_t stream, Elem elem, PlaneRun main, PlaneRun re
 // ---- luma statistics (white bookend-frame detection, the step before the scoring path) ----------
 constexpr int kLumaBlocks = 128;
 // out: [n_frames][3] uint64 = {sum, sum of squares, count(sample > threshold)}; partials: [n_frames][kLumaBlocks][3].
+// gray_bit_depth 0: statistics of the samples as they are; 8/10/12: of gray = clamp(round((Y - 16 s) * 255 / (219 s)), 0, 255),
+// s = 2^(bpc - 8) -- the limited -> full range expansion behind cv2's BGR2GRAY --, threshold in those 8-bit units.
 hipError_t launch_luma_stats(hipStream_t stream, Elem elem, PlaneRun luma, int n_frames, int w, int h,
-                             unsigned threshold, unsigned long long* partials, unsigned long long* out);
+                             unsigned threshold, int gray_bit_depth, unsigned long long* partials,
+                             unsigned long long* out);
+void luma_gray_map(int bit_depth, float* a, float* b);   // the f32 (scale, offset) pair the kernel applies
 
 // ---- finalize -------------------------------------------------------------------------------
 // Fixed-order reduction of every partial array of a batch into per-frame records.

@@ -4,6 +4,13 @@
 // app/reference_analyzer.py:127-144).  Here the three reductions are exact integers per frame
 // (sum, sum of squares, count above threshold); mean / std / ratio follow on the host in float64.
 // Pure streaming: one 16-byte load per lane per step, v_dot4_u32_u8 for both sums -> HBM-bound.
+//
+// Gray convention (pqa_set_luma_gray).  The reference's `gray` is cv2.cvtColor(BGR2GRAY) of a frame that cv2.VideoCapture
+// has already converted from limited-range YUV to full-range BGR: with BT.601 on both legs the chroma terms cancel and
+// gray = clamp(round((Y - 16) * 255 / 219), 0, 255), an 8-bit number whatever the clip's bit depth.  MAP = true applies
+// exactly that map per sample before the three reductions (one v_cvt_f32_ubyte + v_fma_f32 + v_cvt_pk_u8_f32 per sample:
+// the convert rounds to nearest and saturates to 0..255, the small bias makes the exact .5 cases of 10/12-bit samples
+// round up like floor(x + 0.5)); the statistics are then those of the mapped 8-bit gray and the threshold is in its units.
 #include "kernels.h"
 #include "pqa_device.h"
 
@@ -15,8 +22,22 @@ struct LumaArgs {
   int64_t row_pitch, frame_pitch;
   int w, h;
   unsigned threshold;
+  float map_a, map_b;            // MAP: gray = sat_u8(rne(sample * map_a + map_b))
   unsigned long long* partials;  // [n_frames][kLumaBlocks][3]
 };
+
+__device__ __forceinline__ unsigned gray_u8(float sample, float a, float b) {   // one mapped sample in bits 0..7
+  return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(sample, a, b), 0u, 0u);
+}
+// four u8 samples of a dword -> their four gray bytes, same positions
+__device__ __forceinline__ unsigned gray4_u8(unsigned x, float a, float b) {
+  unsigned g = 0;
+  g = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(x & 0xffu), a, b), 0u, g);
+  g = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)((x >> 8) & 0xffu), a, b), 1u, g);
+  g = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)((x >> 16) & 0xffu), a, b), 2u, g);
+  g = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(x >> 24), a, b), 3u, g);
+  return g;
+}
 
 __device__ __forceinline__ unsigned count_gt4(unsigned x, unsigned thr) {
   unsigned c = 0;
@@ -25,7 +46,7 @@ __device__ __forceinline__ unsigned count_gt4(unsigned x, unsigned thr) {
   return c;
 }
 
-template <typename T>
+template <typename T, bool MAP>
 __global__ __launch_bounds__(kBlock) void luma_stats_kernel(const LumaArgs a) {
   __shared__ unsigned long long red[12];
   const int fr = blockIdx.y;
@@ -39,11 +60,16 @@ __global__ __launch_bounds__(kBlock) void luma_stats_kernel(const LumaArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (sizeof(T) == 1) {
-        rs = __builtin_amdgcn_udot4(xs[i], 0x01010101u, rs, false);
-        rq = __builtin_amdgcn_udot4(xs[i], xs[i], rq, false);
-        rc += count_gt4(xs[i], a.threshold);
+        const unsigned g = MAP ? gray4_u8(xs[i], a.map_a, a.map_b) : xs[i];
+        rs = __builtin_amdgcn_udot4(g, 0x01010101u, rs, false);
+        rq = __builtin_amdgcn_udot4(g, g, rq, false);
+        rc += count_gt4(g, a.threshold);
       } else {
-        const unsigned lo = xs[i] & 0xffffu, hi = xs[i] >> 16;
+        unsigned lo = xs[i] & 0xffffu, hi = xs[i] >> 16;
+        if constexpr (MAP) {
+          lo = gray_u8((float)lo, a.map_a, a.map_b);
+          hi = gray_u8((float)hi, a.map_a, a.map_b);
+        }
         sum += lo + hi;
         sq += (unsigned long long)lo * lo + (unsigned long long)hi * hi;
         rc += (lo > a.threshold ? 1u : 0u) + (hi > a.threshold ? 1u : 0u);
@@ -71,7 +97,8 @@ __global__ __launch_bounds__(kBlock) void luma_stats_kernel(const LumaArgs a) {
       unsigned rs = 0, rq = 0, rc = 0;  // per-row 32-bit accumulators (8-bit rows cannot overflow them)
       for (int v = tid; v < wv; v += kBlock) eat(reinterpret_cast<const uint4*>(row)[v], rs, rq, rc);
       for (int x = wv * VEC + tid; x < a.w; x += kBlock) {
-        const unsigned v = row[x];
+        unsigned v = row[x];
+        if constexpr (MAP) v = gray_u8((float)v, a.map_a, a.map_b);
         sum += v;
         sq += (unsigned long long)v * v;
         rc += v > a.threshold ? 1u : 0u;
@@ -110,16 +137,35 @@ __global__ __launch_bounds__(kBlock) void luma_stats_finalize(const unsigned lon
 
 }  // namespace
 
+void luma_gray_map(int bit_depth, float* a, float* b) {
+  // gray = floor((Y - 16 s) * 255 / (219 s) + 0.5), s = 2^(bpc - 8): as one f32 fma followed by a round-to-nearest-even
+  // convert.  Exact .5 cases exist from 10 bit up (Y - 64 = 146 (2k + 1)); the nearest non-tie sits 1 / (876 s / 4) away,
+  // so a bias of a quarter of that turns every tie into "up" and moves nothing else (tests/test_bookend.py walks every
+  // sample value of 8, 10 and 12 bit through this arithmetic in numpy).
+  const double s = (double)(1 << (bit_depth - 8));
+  *a = (float)(255.0 / (219.0 * s));
+  *b = (float)(-16.0 * 255.0 / 219.0 + 0.25 / (219.0 * s));
+}
+
 hipError_t launch_luma_stats(hipStream_t stream, Elem elem, PlaneRun luma, int n_frames, int w, int h,
-                             unsigned threshold, unsigned long long* partials, unsigned long long* out) {
+                             unsigned threshold, int gray_bit_depth, unsigned long long* partials,
+                             unsigned long long* out) {
   if (n_frames <= 0) return hipSuccess;
   LumaArgs a{};
   a.base = luma.base; a.row_pitch = luma.row_pitch; a.frame_pitch = luma.frame_pitch;
   a.w = w; a.h = h; a.threshold = threshold; a.partials = partials;
+  const bool map = gray_bit_depth > 0;   // 0: statistics of the samples as they are
+  if (map) luma_gray_map(gray_bit_depth, &a.map_a, &a.map_b);
   const dim3 grid(kLumaBlocks, n_frames), block(kBlock);
   switch (elem) {
-    case ELEM_U8: hipLaunchKernelGGL((luma_stats_kernel<uint8_t>), grid, block, 0, stream, a); break;
-    case ELEM_U16: hipLaunchKernelGGL((luma_stats_kernel<uint16_t>), grid, block, 0, stream, a); break;
+    case ELEM_U8:
+      if (map) hipLaunchKernelGGL((luma_stats_kernel<uint8_t, true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((luma_stats_kernel<uint8_t, false>), grid, block, 0, stream, a);
+      break;
+    case ELEM_U16:
+      if (map) hipLaunchKernelGGL((luma_stats_kernel<uint16_t, true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((luma_stats_kernel<uint16_t, false>), grid, block, 0, stream, a);
+      break;
     default: return hipErrorInvalidValue;
   }
   hipLaunchKernelGGL(luma_stats_finalize, dim3(n_frames), dim3(kBlock), 0, stream, partials, kLumaBlocks, out);

@@ -201,6 +201,8 @@ struct pqa_ctx {
   hipEvent_t luma_copied[2] = {nullptr, nullptr};
   int64_t luma_pitch = 0;
   int LB = 0;
+  bool luma_ready = false;
+  uint32_t luma_gray = PQA_GRAY_LUMA;
   // motion continuity
   uint8_t* last_luma = nullptr;
   int64_t last_luma_pitch = 0;  // bytes
@@ -232,6 +234,7 @@ struct pqa_ctx {
   std::vector<void*> allocs;
   // profiling
   bool multi_stream = false;
+  bool trace = false;   // PQA_TRACE=1: synchronise after every launch and name it on stderr (localises a stall)
   bool prof = false;
   uint32_t prof_mask = 0xffffffffu;
   std::vector<ProfEv> evs;
@@ -282,17 +285,28 @@ struct ProfScope {
   bool on;
   hipStream_t st;
   ProfScope(pqa_ctx* ctx, int id, int frames, hipStream_t stream)
-      : c(ctx), on(ctx->prof && ((ctx->prof_mask >> id) & 1u)), st(stream) {
+      : c(ctx), on(ctx->prof && ((ctx->prof_mask >> id) & 1u)), st(stream), ev_id(id), ev_frames(frames) {
+    if (c->trace) {
+      fprintf(stderr, "[pqa trace] %s queued\n", kProfNames[id]);
+      fflush(stderr);
+    }
     if (!on) return;
     ev.id = id; ev.frames = frames;
     if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
     hipEventRecord(ev.a, st);
   }
   ~ProfScope() {
+    if (c->trace) {   // the launches of this scope are queued: wait for them and say so, flushed
+      const hipError_t e = hipStreamSynchronize(st);
+      fprintf(stderr, "[pqa trace] %s done (%d frames)%s%s\n", kProfNames[ev_id], ev_frames, e == hipSuccess ? "" : ": ",
+              e == hipSuccess ? "" : hipGetErrorString(e));
+      fflush(stderr);
+    }
     if (!on) return;
     hipEventRecord(ev.b, st);
     c->evs.push_back(ev);
   }
+  int ev_id = 0, ev_frames = 0;
 };
 
 void prof_drain(pqa_ctx* c) {
@@ -790,6 +804,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   {
     const char* e = getenv("PQA_MULTI_STREAM");  // experiment switch: overlap the VIF / ADM / motion chains
     c->multi_stream = e && e[0] == '1';
+    const char* t = getenv("PQA_TRACE");
+    c->trace = t && t[0] == '1';
   }
   for (int i = 0; i < 2; ++i) {
     CREATE_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
@@ -1275,7 +1291,8 @@ int pqa_luma_stats_device(pqa_ctx* c, const void* luma, int64_t row_pitch, int64
     for (int g0 = 0; g0 < group;) {
       const int n = group - g0 < c->B ? group - g0 : c->B;
       const PlaneRun run{(const uint8_t*)luma + (int64_t)(done + g0) * frame_pitch, row_pitch / c->esize, frame_pitch / c->esize};
-      HIPCHK(c, launch_luma_stats(c->stream, c->elem, run, n, c->pw[0], c->ph[0], threshold, c->luma_part,
+      HIPCHK(c, launch_luma_stats(c->stream, c->elem, run, n, c->pw[0], c->ph[0], threshold,
+                                  c->luma_gray == PQA_GRAY_BT601_FULL ? (int)c->cfg.bit_depth : 0, c->luma_part,
                                   c->luma_out + (size_t)g0 * 3));
       g0 += n;
     }
@@ -1293,41 +1310,81 @@ int pqa_luma_stats(pqa_ctx* c, const void* const* luma_frames, int64_t row_strid
   if (n_frames < 0 || (n_frames > 0 && (!luma_frames || !out))) return fail(c, PQA_EINVAL, "bad argument");
   const size_t row_bytes = (size_t)c->pw[0] * c->esize;
   if (n_frames > 0 && (size_t)row_stride < row_bytes) return fail(c, PQA_EINVAL, "stride smaller than a row");
+  for (int f = 0; f < n_frames; ++f)   // before anything is queued
+    if (!luma_frames[f]) return fail(c, PQA_EINVAL, "frame %d pointer is null", f);
   if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
   HIPCHK(c, hipSetDevice(c->device));
   const int h = c->ph[0];
-  if (!c->luma_pinned[0]) {  // lazily: most contexts never detect bookends
+  if (!c->luma_ready) {  // lazily: most contexts never detect bookends
     c->luma_pitch = round_up((int64_t)row_bytes, 64);
     c->LB = c->B < 8 ? c->B : 8;
     const size_t half = (size_t)c->luma_pitch * h * c->LB;
-    for (int i = 0; i < 2; ++i) {
-      HIPCHK(c, hipHostMalloc((void**)&c->luma_pinned[i], half, hipHostMallocDefault));
-      HIPCHK(c, hipMalloc((void**)&c->luma_dev[i], half));
-      HIPCHK(c, hipEventCreateWithFlags(&c->luma_copied[i], hipEventDisableTiming));
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+      if (!c->luma_pinned[i]) e = hipHostMalloc((void**)&c->luma_pinned[i], half, hipHostMallocDefault);
+      if (e == hipSuccess && !c->luma_dev[i]) e = hipMalloc((void**)&c->luma_dev[i], half);
+      if (e == hipSuccess && !c->luma_copied[i]) e = hipEventCreateWithFlags(&c->luma_copied[i], hipEventDisableTiming);
     }
+    if (e != hipSuccess) {   // all six or none: a half-made set must not make every later call fail on a null handle
+      for (int i = 0; i < 2; ++i) {
+        if (c->luma_pinned[i]) hipHostFree(c->luma_pinned[i]);
+        if (c->luma_dev[i]) hipFree(c->luma_dev[i]);
+        if (c->luma_copied[i]) hipEventDestroy(c->luma_copied[i]);
+        c->luma_pinned[i] = c->luma_dev[i] = nullptr;
+        c->luma_copied[i] = nullptr;
+      }
+      return fail(c, e == hipErrorOutOfMemory ? PQA_ENOMEM : PQA_EDEVICE, "luma staging allocation failed: %s", hipGetErrorString(e));
+    }
+    c->luma_ready = true;
   }
   const size_t frame_bytes = (size_t)c->luma_pitch * h;
+  const int gray_bpc = c->luma_gray == PQA_GRAY_BT601_FULL ? (int)c->cfg.bit_depth : 0;
+  // Chunks of LB frames alternate between two pinned / device halves; every chunk's kernel writes its results next to the
+  // previous ones in luma_out, and the host gets them in ONE copy + sync per kLumaOutFrames frames: no device-to-host copy
+  // sits between the chunks (into the caller's pageable `out` it would block the host until the kernel in front of it is
+  // done, and the next chunk could not be packed under that kernel).
+  int rc = PQA_OK;
   int chunk = 0;
-  for (int done = 0; done < n_frames; ++chunk) {
-    if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
-    const int n = n_frames - done < c->LB ? n_frames - done : c->LB;
-    const int hf = chunk & 1;
-    if (chunk >= 2) HIPCHK(c, hipEventSynchronize(c->luma_copied[hf]));  // the upload two chunks ago has left this half
-    for (int f = 0; f < n; ++f) {
-      if (!luma_frames[done + f]) return fail(c, PQA_EINVAL, "frame %d pointer is null", done + f);
-      copy_plane_rows(c->luma_pinned[hf] + (size_t)f * frame_bytes, c->luma_pitch, (const uint8_t*)luma_frames[done + f],
-                      row_stride, row_bytes, h);
+  for (int done = 0; done < n_frames && rc == PQA_OK;) {
+    const int group = n_frames - done < kLumaOutFrames ? n_frames - done : kLumaOutFrames;
+    for (int g0 = 0; g0 < group && rc == PQA_OK; ++chunk) {
+      if (c->cancelled.load()) { rc = fail(c, PQA_ECANCELLED, "cancelled"); break; }
+      const int n = group - g0 < c->LB ? group - g0 : c->LB;
+      const int hf = chunk & 1;
+      hipError_t e = hipSuccess;
+      if (chunk >= 2) e = hipEventSynchronize(c->luma_copied[hf]);   // the upload two chunks ago has left this pinned half
+      if (e == hipSuccess) {
+        for (int f = 0; f < n; ++f)
+          copy_plane_rows(c->luma_pinned[hf] + (size_t)f * frame_bytes, c->luma_pitch, (const uint8_t*)luma_frames[done + g0 + f],
+                          row_stride, row_bytes, h);
+        e = hipMemcpyAsync(c->luma_dev[hf], c->luma_pinned[hf], (size_t)n * frame_bytes, hipMemcpyHostToDevice, c->stream);
+      }
+      if (e == hipSuccess) e = hipEventRecord(c->luma_copied[hf], c->stream);
+      if (e == hipSuccess) {
+        const PlaneRun run{c->luma_dev[hf], c->luma_pitch / c->esize, (int64_t)(frame_bytes / c->esize)};
+        e = launch_luma_stats(c->stream, c->elem, run, n, c->pw[0], h, threshold, gray_bpc, c->luma_part,
+                              c->luma_out + (size_t)g0 * 3);
+      }
+      if (e != hipSuccess) { rc = fail(c, PQA_EDEVICE, "luma statistics chunk failed: %s", hipGetErrorString(e)); break; }
+      g0 += n;
     }
-    HIPCHK(c, hipMemcpyAsync(c->luma_dev[hf], c->luma_pinned[hf], (size_t)n * frame_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->luma_copied[hf], c->stream));
-    const PlaneRun run{c->luma_dev[hf], c->luma_pitch / c->esize, (int64_t)(frame_bytes / c->esize)};
-    HIPCHK(c, launch_luma_stats(c->stream, c->elem, run, n, c->pw[0], h, threshold, c->luma_part, c->luma_out));
-    // stream-ordered: this copy is queued before the next chunk's kernel rewrites luma_out
-    HIPCHK(c, hipMemcpyAsync(out + (size_t)done * 3, c->luma_out, (size_t)n * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                             c->stream));
-    done += n;
+    if (rc == PQA_OK) {
+      const hipError_t e = hipMemcpyAsync(out + (size_t)done * 3, c->luma_out, (size_t)group * 3 * sizeof(uint64_t),
+                                          hipMemcpyDeviceToHost, c->stream);
+      if (e != hipSuccess) rc = fail(c, PQA_EDEVICE, "luma statistics copy failed: %s", hipGetErrorString(e));
+    }
+    // always: nothing queued on the stream may still point at the pinned halves or at `out` when this call returns
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    if (es != hipSuccess && rc == PQA_OK) rc = fail(c, PQA_EDEVICE, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
+    done += group;
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return rc;
+}
+
+int pqa_set_luma_gray(pqa_ctx* c, uint32_t mode) {
+  if (!c) return PQA_EINVAL;
+  if (mode != PQA_GRAY_LUMA && mode != PQA_GRAY_BT601_FULL) return fail(c, PQA_EINVAL, "bad gray mode %u", mode);
+  c->luma_gray = mode;
   return PQA_OK;
 }
 

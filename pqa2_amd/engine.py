@@ -120,6 +120,11 @@ class FeatureEngine:
         self._check(self.lib.pqa_submit_surfaces(self._ctx, first_index, n_frames, C.byref(ref), C.byref(dis),
                                                  C.byref(prev_ref) if prev_ref is not None else None))
 
+    def set_luma_gray(self, mode: int):
+        """N.GRAY_LUMA: statistics of the luma samples; N.GRAY_BT601_FULL: of the limited -> full range gray the
+        reference's cv2 path sees (8-bit units for every bit depth; thresholds in those units)."""
+        self._check(self.lib.pqa_set_luma_gray(self._ctx, int(mode)))
+
     def luma_stats_resident(self, luma_ptr: int, row_pitch: int, frame_pitch: int, n_frames: int,
                             threshold: int) -> np.ndarray:
         """[n,3] uint64 {sum, sum of squares, count(sample > threshold)} per frame of a clip in HBM."""

@@ -21,7 +21,7 @@ def _texture(h: int, w: int, gen: torch.Generator, device) -> torch.Tensor:
 
 
 def make_clip_cuda(w: int, h: int, n: int, bit_depth: int = 8, seed: int = 20250418, device="cuda",
-                   chroma: bool = False, t0: int = 0):
+                   chroma: bool = False, t0: int = 0, progress=None):
     """Returns dict with 'ref' and 'dis': lists of per-plane tensors [n, ph, pw] (uint8 / int16-as-uint16 view)."""
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
@@ -59,6 +59,9 @@ def make_clip_cuda(w: int, h: int, n: int, bit_depth: int = 8, seed: int = 20250
             ref[i] = (r * scale + lsb).round().clamp_(0, peak).to(torch.int16)
             dis[i] = (d * scale + lsb).round().clamp_(0, peak).to(torch.int16)
     out = {"ref": [ref], "dis": [dis]}
+    if progress:
+        torch.cuda.synchronize(dev)
+        progress("luma planes generated")
     if chroma:
         cw, ch = (w + 1) // 2, (h + 1) // 2
         cy, cx = torch.meshgrid(torch.arange(ch, device=dev, dtype=torch.float32),
@@ -77,4 +80,7 @@ def make_clip_cuda(w: int, h: int, n: int, bit_depth: int = 8, seed: int = 20250
                     cd[i] = (e * scale).round().clamp_(0, peak).to(torch.int16)
             out["ref"].append(cr)
             out["dis"].append(cd)
+            if progress:
+                torch.cuda.synchronize(dev)
+                progress(f"chroma plane {len(out['ref']) - 1} generated")
     return out

@@ -37,6 +37,7 @@ class VideoInfo:
     fps_den: int = 1
     n_frames: int = 0
     chroma_tag: str = "420jpeg"
+    color_range: str | None = None   # "limited" / "full" when the container says so (Y4M XCOLORRANGE=...), else None
 
     @property
     def dtype(self):
@@ -103,6 +104,8 @@ class Y4MReader:
                     raise ValueError(f"unsupported Y4M chroma tag C{v}")
                 info.hshift, info.vshift, info.bit_depth, info.mono = _Y4M_CHROMA[v]
                 info.chroma_tag = v
+            elif k == "X" and v.upper().startswith("COLORRANGE="):   # FFmpeg's Y4M extension
+                info.color_range = {"FULL": "full", "LIMITED": "limited"}.get(v.split("=", 1)[1].upper())
         if info.width <= 0 or info.height <= 0:
             raise ValueError("Y4M header lacks W/H")
         self.info = info
@@ -201,7 +204,8 @@ class RawYUVReader:
 def write_y4m(path: str, frames, info: VideoInfo) -> None:
     """frames: iterable of [Y,U,V] plane lists matching `info`."""
     with open(path, "wb") as f:
-        f.write(f"YUV4MPEG2 W{info.width} H{info.height} F{info.fps_num}:{info.fps_den} Ip A1:1 C{info.chroma_tag}\n".encode())
+        f.write(f"YUV4MPEG2 W{info.width} H{info.height} F{info.fps_num}:{info.fps_den} Ip A1:1 C{info.chroma_tag}"
+                f"{' XCOLORRANGE=' + info.color_range.upper() if info.color_range else ''}\n".encode())
         for planes in frames:
             f.write(b"FRAME\n")
             for p in planes:

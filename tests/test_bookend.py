@@ -30,10 +30,21 @@ def _clip_with_bookends(tmp_path, w, h, n, fps, white_runs, bpc=8, white_level=2
     return p, frames
 
 
-def _reference_style_detect(frames, fps, bpc=8, frame_sampling_rate=5, adaptive=True, white_threshold=230, fallback=True):
+def _cv2_style_gray(y, bpc):
+    """What cv2.cvtColor(BGR2GRAY) of cv2.VideoCapture's full-range BGR frame holds for a limited-range luma plane when
+    both legs are BT.601 (the chroma terms cancel): an 8-bit image, written here in floating point per pixel."""
+    s = float(1 << (bpc - 8))
+    return np.clip(np.floor((y.astype(np.float64) - 16.0 * s) * 255.0 / (219.0 * s) + 0.5), 0, 255)
+
+
+def _reference_style_detect(frames, fps, bpc=8, frame_sampling_rate=5, adaptive=True, white_threshold=230, fallback=True,
+                            gray="luma"):
     """Sequential restatement of the reference loop: every decision from np.mean / np.std / np.sum(gray > t)."""
     scale = float(1 << (bpc - 8))
-    gray_of = lambda i: frames[i][0].astype(np.float64) / scale
+    if gray == "bt601_full":
+        gray_of = lambda i: _cv2_style_gray(frames[i][0], bpc)
+    else:
+        gray_of = lambda i: frames[i][0].astype(np.float64) / scale
     frame_count = len(frames)
     duration = frame_count / fps
     sample_interval = max(1, int(fps / frame_sampling_rate))
@@ -155,15 +166,17 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("gray", ["luma", "bt601_full"])
 @pytest.mark.parametrize("fps,n,runs,kw", CASES)
-def test_detect_matches_the_reference_style_loop(tmp_path, fps, n, runs, kw):
+def test_detect_matches_the_reference_style_loop(tmp_path, fps, n, runs, kw, gray):
     w, h = 96, 64
-    path, frames = _clip_with_bookends(tmp_path, w, h, n, fps, runs, partial=(runs[0][1] + 1, 0.8) if runs else None)
+    path, frames = _clip_with_bookends(tmp_path, w, h, n, fps, runs, partial=(runs[0][1] + 1, 0.8) if runs else None,
+                                       white_level=250 if gray == "luma" else 233)
     rd = yuvio.open_video(path)
-    got = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd), **kw)
+    got = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd, gray), gray=gray, **kw)
     want = _reference_style_detect(frames, fps, adaptive=kw.get("adaptive_brightness", True),
                                    white_threshold=kw.get("white_threshold", 230),
-                                   fallback=kw.get("fallback_to_full_video", True))
+                                   fallback=kw.get("fallback_to_full_video", True), gray=gray)
     _same(got, want)
     if len(runs) >= 2:
         assert got[0]["start_frame"] == runs[0][0] and got[-1]["end_frame"] == runs[-1][1]
@@ -176,9 +189,71 @@ def test_detect_10bit_uses_8bit_gray_units(tmp_path):
     runs = [(5, 14), (100, 110)]
     path, frames = _clip_with_bookends(tmp_path, w, h, n, fps, runs, bpc=10)
     rd = yuvio.open_video(path)
-    got = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd))
+    got = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd), gray="luma")
     _same(got, _reference_style_detect(frames, fps, bpc=10))
     assert [(b["start_frame"], b["end_frame"]) for b in got] == runs
+    # and through the range expansion: the kernel's gray is 8-bit whatever the depth
+    got = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd, "bt601_full"), gray="bt601_full")
+    _same(got, _reference_style_detect(frames, fps, bpc=10, gray="bt601_full"))
+    assert [(b["start_frame"], b["end_frame"]) for b in got] == runs
+
+
+def test_limited_range_white_is_found_like_its_expanded_twin(tmp_path):
+    """ADVICE r2 / VERDICT r2 #8: a TV-range capture whose white is Y = 235 must go through the fixed white_threshold = 230
+    path exactly as the same pictures stored full range do (that is what the reference's cv2 gray gives it): same sections,
+    same brightness and std_dev, because the reductions are taken over the expanded gray per sample."""
+    w, h, fps, n, runs = 96, 64, 30, 120, [(6, 15), (100, 111)]
+    rng = np.random.default_rng(11)
+    lim = []
+    for t in range(n):
+        y = 16.0 + synth.ref_luma(w, h, t) * (150.0 / 255.0)          # content inside 16..166
+        if any(a <= t <= b for a, b in runs):
+            y = 235.0 - np.abs(rng.normal(0, 0.7, (h, w)))           # TV white with a little sensor noise, never above 235
+        lim.append([np.clip(np.rint(y), 16, 235).astype(np.uint8)])
+    full = [[bookend.expand_bt601_full(f[0], 8).astype(np.uint8)] for f in lim]
+    assert full[runs[0][0]][0].max() == 255 and lim[runs[0][0]][0].max() == 235
+    info = synth.clip_info(w, h, 8, chroma=False, fps=fps)
+    p_lim, p_full = str(tmp_path / "lim.y4m"), str(tmp_path / "full.y4m")
+    yuvio.write_y4m(p_lim, lim, info)
+    info_full = synth.clip_info(w, h, 8, chroma=False, fps=fps)
+    info_full.color_range = "full"
+    yuvio.write_y4m(p_full, full, info_full)
+    r_lim, r_full = yuvio.open_video(p_lim), yuvio.open_video(p_full)
+    assert r_lim.info.color_range is None and r_full.info.color_range == "full"
+    assert bookend.resolve_gray("auto", r_lim.info) == "bt601_full" and bookend.resolve_gray("auto", r_full.info) == "luma"
+    kw = dict(adaptive_brightness=False, white_threshold=230)
+    a = bookend.detect(r_lim, stats_fn=bookend.numpy_stats_fn(r_lim, "auto"), **kw)       # gray="auto" -> expansion
+    b = bookend.detect(r_full, stats_fn=bookend.numpy_stats_fn(r_full, "auto"), **kw)     # gray="auto" -> luma as it is
+    assert a == b and [(x["start_frame"], x["end_frame"]) for x in a] == runs
+    assert a[0]["brightness"] > 250                                    # 235 has become (almost) 255
+    _same(a, _reference_style_detect(lim, fps, adaptive=False, white_threshold=230, gray="bt601_full"))
+    # reference_analyzer.py:134's "85 % of the pixels above 200" on a dim TV white (Y = 190 -> gray 203): only the
+    # expanded gray passes it
+    dim = [[np.full((h, w), 190, np.uint8)]] * 3
+    yuvio.write_y4m(str(tmp_path / "dim.y4m"), dim, info)
+    r_dim = yuvio.open_video(str(tmp_path / "dim.y4m"))
+    ratio = lambda g: bookend.brightness_from_stats(bookend.numpy_stats_fn(r_dim, g)([0, 1, 2], 200), w * h)[2]
+    assert bookend.starts_with_bookend(ratio("bt601_full")) and not bookend.starts_with_bookend(ratio("luma"))
+
+
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+def test_kernel_gray_arithmetic_is_the_integer_map_for_every_sample_value(bpc):
+    """csrc/luma_stats.hip maps a sample with ONE f32 fma and a round-to-nearest-even, saturating convert
+    (v_cvt_pk_u8_f32), scale and biased offset from luma_gray_map().  Walk every sample value of the depth through that
+    arithmetic in numpy (f64 product + sum rounded once to f32 = the fma) and require bookend.expand_bt601_full's integers,
+    the exact .5 cases of 10 / 12 bit included."""
+    s = float(1 << (bpc - 8))
+    a = np.float32(255.0 / (219.0 * s))
+    b = np.float32(-16.0 * 255.0 / 219.0 + 0.25 / (219.0 * s))
+    y = np.arange(1 << bpc)
+    fma = (y.astype(np.float64) * np.float64(a) + np.float64(b)).astype(np.float32)
+    got = np.clip(np.rint(fma.astype(np.float64)), 0, 255).astype(np.uint64)        # rint = round half to even
+    want = bookend.expand_bt601_full(y, bpc)
+    assert np.array_equal(got, want)
+    assert np.array_equal(want, _cv2_style_gray(y, bpc).astype(np.uint64))
+    if bpc > 8:                                                                        # the ties exist and round up
+        tie = 16 * int(s) + 146 * int(s) // 4
+        assert ((tie - 16 * s) * 255.0 / (219.0 * s)) % 1.0 == 0.5 and want[tie] == int((tie - 16 * s) * 255.0 / (219.0 * s)) + 1
 
 
 def test_detect_needs_an_engine_or_stats_fn(tmp_path):
@@ -201,8 +276,21 @@ def test_detect_on_the_gpu_engine(tmp_path, bpc, w, h):
         idx = list(range(0, n, 7))
         st = eng.luma_stats([rd.frame(i)[0] for i in idx], 200 << (bpc - 8))
         assert np.array_equal(st, bookend.numpy_stats_fn(rd)(idx, 200 << (bpc - 8)))
-        got = bookend.detect(rd, eng)
-    cpu = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd))
+        # the range expansion inside the kernel: exact integers of the 8-bit gray, threshold in its units
+        from pqa2_amd import _native as N
+        eng.set_luma_gray(N.GRAY_BT601_FULL)
+        st = eng.luma_stats([rd.frame(i)[0] for i in idx], 200)
+        assert np.array_equal(st, bookend.numpy_stats_fn(rd, "bt601_full")(idx, 200))
+        # every sample value of the depth at once (a ramp), ties of the deeper formats included
+        ramp = (np.arange(w * h, dtype=np.int64) % (1 << bpc)).reshape(h, w).astype(rd.info.dtype)
+        g = bookend.expand_bt601_full(ramp, bpc)
+        assert np.array_equal(eng.luma_stats([ramp], 128)[0], np.array([g.sum(), (g * g).sum(), (g > 128).sum()], np.uint64))
+        eng.set_luma_gray(N.GRAY_LUMA)
+        got = bookend.detect(rd, eng, gray="luma")
+        got_full = bookend.detect(rd, eng, gray="bt601_full")
+    cpu = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd), gray="luma")
     assert got == cpu                       # same integers in, same floats out
+    assert got_full == bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd, "bt601_full"), gray="bt601_full")
     _same(got, _reference_style_detect(frames, fps, bpc=bpc))
+    _same(got_full, _reference_style_detect(frames, fps, bpc=bpc, gray="bt601_full"))
     assert [(b["start_frame"], b["end_frame"]) for b in got][0][0] == runs[0][0]

@@ -45,7 +45,7 @@ with FeatureEngine(w, h, max_batch=64) as eng:
                      "what": "bookend.detect on a Y4M file: brightness sampling + coarse scan + frame-accurate scan of the candidate "
                              "regions (the reference seeks and decodes the same frames with cv2, bookend_alignment.py:755-1133)"}
     t0 = time.perf_counter()
-    cpu = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd))
+    cpu = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd, "auto"))
     out["detect_numpy"] = {"clip_frames_per_s": round(n / (time.perf_counter() - t0), 1), "same_result": cpu == found}
     os.remove(path); os.rmdir(d)
 print(json.dumps(out))
