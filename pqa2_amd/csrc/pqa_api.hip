@@ -181,6 +181,7 @@ struct pqa_ctx {
   AdmFxScale adm_fx[4] = {};
   unsigned long long* motion_fx_part = nullptr;
   int vif_tiles[4] = {};
+  int vif_part_cap0 = 0;   // partial pairs per frame the scale-0 buffer holds (tiled kernels or the march kernel)
   double* adm_part[4] = {};
   int adm_tiles[4] = {};
   float adm_area[4] = {};
@@ -234,6 +235,7 @@ struct pqa_ctx {
   std::vector<void*> allocs;
   // profiling
   bool multi_stream = false;
+  int vif_s0_mode = VIF_S0_AUTO;   // PQA_VIF_MFMA, read once in pqa_create
   bool trace = false;   // PQA_TRACE=1: synchronise after every launch and name it on stderr (localises a stall)
   bool prof = false;
   uint32_t prof_mask = 0xffffffffu;
@@ -409,10 +411,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     }
     if (p0 && p0_pitch % es) return fail(c, PQA_EINVAL, "halo pitch is not a multiple of the sample size");
   }
-  // the matrix-core VIF kernel can produce the motion SAD from the reference frames it reads anyway (csrc/vif.hip)
-  const bool try_fuse = (feat & PQA_FEAT_MOTION) && (feat & PQA_FEAT_VIF) && !c->vif_fixed && !c->motion_fixed && k == 1 &&
-                        c->cfg.bit_depth <= 10;
-  bool motion_fused = false;
+  int vif_np[4] = {c->vif_tiles[0], c->vif_tiles[1], c->vif_tiles[2], c->vif_tiles[3]};   // partial pairs written per frame
 
   if ((feat & PQA_FEAT_VIF) && sp_n > 0 && c->vif_fixed) {
     PlaneRun cr = rYs, cd = dYs;
@@ -451,10 +450,9 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       }
       {
         ProfScope ps(c, s, sp_n, st);
-        const VifMotionFusion mo{p0, p0 ? p0_pitch / es : 0, c->motion_part};
         HIPCHK(c, launch_vif_stat(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
                                   (float)c->cfg.vif_enhn_gain_limit, c->cfg.vif_border == PQA_VIF_BORDER_INTEGER,
-                                  c->vif_part[s], nr, nd, (s == 0 && try_fuse) ? &mo : nullptr, s == 0 ? &motion_fused : nullptr));
+                                  c->vif_part[s], nr, nd, c->vif_s0_mode, &vif_np[s]));
       }
       if (s < 3) {
         Level& L = c->vif_lv[s + 1];
@@ -514,7 +512,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       }
     }
   }
-  if ((feat & PQA_FEAT_MOTION) && !motion_fused) {
+  if (feat & PQA_FEAT_MOTION) {
     ProfScope ps(c, 11, n, st_misc);
     if (c->motion_fixed)
       HIPCHK(c, launch_motion_fixed(st_misc, (int)c->cfg.bit_depth, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h,
@@ -574,7 +572,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
 
   FinalizeArgs fa{};
   for (int s = 0; s < 4; ++s) {
-    fa.vif_part[s] = c->vif_part[s]; fa.vif_tiles[s] = c->vif_tiles[s];
+    fa.vif_part[s] = c->vif_part[s]; fa.vif_tiles[s] = c->vif_fixed ? c->vif_tiles[s] : vif_np[s];
     fa.vif_fx_part[s] = c->vif_fixed ? c->vif_fx_part[s] : nullptr;
     fa.adm_part[s] = c->adm_part[s]; fa.adm_tiles[s] = c->adm_tiles[s]; fa.adm_area[s] = c->adm_area[s];
     fa.adm_fx_part[s] = c->adm_fixed ? c->adm_fx_part[s] : nullptr;
@@ -583,7 +581,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     fa.adm_fx_num_shift[s] = c->adm_fx[s].num_row_shift; fa.adm_fx_den_shift[s] = c->adm_fx[s].den_row_shift;
   }
   fa.motion_part = c->motion_part;
-  fa.motion_tiles = motion_fused ? c->vif_tiles[0] : c->motion_tiles_n;   // fused: one SAD partial per VIF tile
+  fa.motion_tiles = c->motion_tiles_n;
   fa.motion_norm = (double)c->inv_scale / ((double)w * h);
   fa.motion_fx_part = c->motion_fixed ? c->motion_fx_part : nullptr;
   fa.motion_wh = (unsigned)w * (unsigned)h;
@@ -806,6 +804,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     c->multi_stream = e && e[0] == '1';
     const char* t = getenv("PQA_TRACE");
     c->trace = t && t[0] == '1';
+    const char* v = getenv("PQA_VIF_MFMA");   // 0: VALU kernels only; 2: the round-2 scale-0 kernel; default: march kernel
+    c->vif_s0_mode = (v && v[0] == '0') ? VIF_S0_VALU : (v && v[0] == '2') ? VIF_S0_SPLIT : VIF_S0_AUTO;
   }
   for (int i = 0; i < 2; ++i) {
     CREATE_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
@@ -832,6 +832,7 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     CREATE_HIP(hipMemcpy(c->adm_div_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   if ((cfg->features & PQA_FEAT_VIF) && !c->vif_fixed && cfg->bit_depth <= 10) CREATE_HIP(vif_mfma_prepare());
+  if ((cfg->features & PQA_FEAT_VIF) && !c->vif_fixed && cfg->bit_depth == 8) CREATE_HIP(vif_march_prepare());
   if (c->vif_fixed) {
     std::vector<uint16_t> lut(32768);
     vif_fixed_log2_table(lut.data());
@@ -860,12 +861,16 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     }
     if (vw < 2 || vh < 2) { fail(c, PQA_EINVAL, "frame too small for 4 VIF scales"); return bail(PQA_EINVAL); }
     c->vif_tiles[s] = vif_tiles_x(s, vw) * vif_tiles_y(vh);
+    if (s == 0) {   // scale 0 may run the march kernel, which writes one partial pair per wave segment
+      const int mp = vif_march_partials_max(vw, vh);
+      c->vif_part_cap0 = c->vif_tiles[0] > mp ? c->vif_tiles[0] : mp;
+    }
     const int bw = (aw + 1) / 2, bh = (ah + 1) / 2;  // band size produced at ADM scale s
     c->adm_tiles[s] = adm_tiles_x(bw) * adm_tiles_y(bh);
     const int left = (int)(bw * 0.1 - 0.5), top = (int)(bh * 0.1 - 0.5);
     c->adm_area[s] = (float)((bh - 2 * top) * (bw - 2 * left));
     if ((cfg->features & PQA_FEAT_VIF) && !c->vif_fixed)
-      CREATE_TRY(dev_alloc(c, &c->vif_part[s], (size_t)c->vif_tiles[s] * 2 * B));
+      CREATE_TRY(dev_alloc(c, &c->vif_part[s], (size_t)(s == 0 ? c->vif_part_cap0 : c->vif_tiles[s]) * 2 * B));
     if ((cfg->features & PQA_FEAT_VIF) && c->vif_fixed)
       CREATE_TRY(dev_alloc(c, &c->vif_fx_part[s], (size_t)c->vif_tiles[s] * kVifFxPartials * B));
     c->adm_fx[s] = adm_fixed_scale_params(s, bw, bh);
@@ -876,8 +881,7 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   }
   c->motion_tiles_n = motion_tiles(w, h);
   if (cfg->features & PQA_FEAT_MOTION) {
-    CREATE_TRY(dev_alloc(c, &c->motion_part,
-                         (size_t)(c->motion_tiles_n > c->vif_tiles[0] ? c->motion_tiles_n : c->vif_tiles[0]) * B));
+    CREATE_TRY(dev_alloc(c, &c->motion_part, (size_t)c->motion_tiles_n * B));
     if (c->motion_fixed) CREATE_TRY(dev_alloc(c, &c->motion_fx_part, (size_t)c->motion_tiles_n * B));
     c->last_luma_pitch = round_up((int64_t)w * c->esize, 64);
     CREATE_TRY(dev_alloc(c, &c->last_luma, (size_t)c->last_luma_pitch * h));

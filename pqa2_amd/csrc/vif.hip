@@ -83,12 +83,6 @@ struct VifStatArgs {
   // Units are tiles for vif_stat_kernel and vertically adjacent tile PAIRS (2p, 2p+1) for vif_s0_mfma_kernel.
   int tx_lo, tx_hi, ty_lo, ty_hi, grid_rows;
   const uint4* atab;   // MFMA kernel: per-lane tap-matrix fragments (kAtabFrags x 64 lanes x 8 f16)
-  // MFMA kernel with fused motion (MOTION variants): the reference luma of the previous frame is the frame before in
-  // the run, or mprev0 for the run's first frame (null: that frame's motion is 0); one SAD partial per tile
-  const void* mprev0;
-  int64_t mprev0_pitch;   // elements
-  double* mpart;          // [n_frames][n_tiles]
-  f2 mt[5];               // horizontal motion taps {c, c}, carrying the 2^-17 of the vertical pass
   int extra_ty;           // >= 0: the last border unit is the pair (extra_ty, extra_ty + 1) of which only the LOWER tile
                           // is new (odd number of tile rows); its upper tile is skipped
   TapPairs taps;
@@ -121,11 +115,8 @@ constexpr int kP2 = 258;  // LDS row pitch in float2: == 2 (mod 32) -> conflict-
 // {ref, dis}.  Shared by the VALU kernel (vif_stat_kernel) and the matrix-core kernel (vif_s0_mfma_kernel).
 // FULL: every pixel of the tile lies inside the image (interior tile pairs of the matrix-core kernel): the validity
 // masks of edge tiles drop out.
-// MOTION: a sixth plane in sv holds the 5-tap vertically blurred frame difference of the reference (x 2^17); its
-// horizontal pass and the absolute sum ride along (sum |blur(cur - prev)| = libvmaf's SAD of the blurred planes, see
-// motion.hip) and the tile's SAD goes to a.mpart.
-template <int N, int TW, int ND, bool FULL = false, bool MOTION = false>
-__device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* [5 or 6][TH/2][kP2] */,
+template <int N, int TW, int ND, bool FULL = false>
+__device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* [5][TH/2][kP2] */,
                                           const f2* sd /* [TH/2][kP2] */, double* red, int fr, int tile, int x0, int y0) {
   constexpr int R = N / 2, TH = kVifTileH, NSEG = TW / 4, NRP = TH / 2;
   constexpr int RD = ND / 2;
@@ -251,39 +242,7 @@ __device__ __forceinline__ void vif_hstat(const VifStatArgs& a, const f2* sv /* 
     num = (num2.x + num2.y) + ((fast_log2(pn.x) - fast_log2(qn.x)) + (fast_log2(pn.y) - fast_log2(qn.y)));
     den = (den2.x + den2.y) + (fast_log2(pd.x) + fast_log2(pd.y));
   }
-  float sad = 0.0f;
-  if (MOTION && seg < NSEG) {
-    f2 in[8];
-    const f4* p = reinterpret_cast<const f4*>(&sv[(5 * NRP + rp) * kP2 + seg * 4 + (R - 2)]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f4 v = p[q];
-      in[2 * q] = f2{v.x, v.y};
-      in[2 * q + 1] = f2{v.z, v.w};
-    }
-    const int gyA = y0 + 2 * rp;
-    const float mA = (FULL || gyA < a.h) ? 1.0f : 0.0f, mB = (FULL || gyA + 1 < a.h) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      f2 m = f2{0.0f, 0.0f};
-#pragma unroll
-      for (int k = 0; k < 5; ++k) m = __builtin_elementwise_fma(a.mt[k], in[o + k], m);
-      const float mc = (FULL || (x0 + seg * 4 + o) < a.w) ? 1.0f : 0.0f;
-      sad = fmaf(mc * mA, fabsf(m.x), sad);
-      sad = fmaf(mc * mB, fabsf(m.y), sad);
-    }
-  }
-  if (MOTION) {
-    const float part[3] = {num, den, sad};
-    double v[3];
-    block_sum_f32<3>(part, v, red);
-    if (tid == 0) {
-      double* out = a.partials + ((int64_t)fr * a.n_tiles + tile) * 2;
-      out[0] = v[0];
-      out[1] = v[1];
-      a.mpart[(int64_t)fr * a.n_tiles + tile] = v[2];
-    }
-  } else {
+  {
     const float part[2] = {num, den};
     double v[2];
     block_sum_f32<2>(part, v, red);
@@ -445,16 +404,8 @@ typedef short s2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 // fragments in the table: 0-2: c*2^19 pieces (high digits)  3-4, 12: c*2^11 pieces (means; 3-4 also the 8-bit low digits)
-// 5-7: c'*2^18 pieces (decimation)  8-9: c*2^9 pieces (10-bit low digits, base 1024)  10-11: motion taps * 2^17, two pieces
+// 5-7: c'*2^18 pieces (decimation)  8-9: c*2^9 pieces (10-bit low digits, base 1024)  10-11: unused
 constexpr int kAtabFrags = 13;
-constexpr float kMfmaMotionScale = 1.0f / 131072.0f;   // 2^-17
-
-static void motion_taps(float f[5]) {  // FILTER_5_s of libvmaf's motion: 5 taps, sigma 1.0 (same table as motion.hip)
-  double v[5], sum = 0.0;
-  for (int k = 0; k < 5; ++k) { v[k] = exp(-0.5 * (k - 2) * (k - 2)); sum += v[k]; }
-  for (int k = 0; k < 5; ++k) f[k] = (float)(v[k] / sum);
-}
-
 // an 8-byte LDS store the compiler may not fuse with its neighbour into a 16-byte one (volatile): the two halves come
 // from different accumulators, and fusing them means four register copies per store
 __device__ __forceinline__ void lds_store_f2(f2* p, f2 v) {
@@ -486,16 +437,12 @@ __device__ __forceinline__ unsigned f16_tiny_minus(unsigned x, unsigned short of
 // lo < 1024: still below 2048) from 32-bit products; the low planes use pieces of c * 2^9, and with the sample scale
 // (1/4 on the means, 1/16 on the squares) every signal comes out as 2^-11 of libvmaf's: again one factor for the
 // horizontal taps.  12-bit clips (squares of 22 bits: three digits) stay on the VALU kernel.
-// MOTION (opt-in experiment, PQA_FUSE_MOTION=1; slower than the standalone motion kernel, see launch_s0_split): the motion
-// feature rides along as a sixth plane -- the exact integer frame difference of the reference luma (|.| <= 255 / 1023: one
-// f16 plane), its 5-tap vertical blur as two more MFMAs per N-block (two-piece taps x 2^17), the horizontal blur and the
-// absolute sum in vif_hstat.  The extra LDS plane takes the kernel from 3 to 2 workgroups per CU.
-template <typename T, bool EDGE, bool MOTION>
-__global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(const VifStatArgs a) {
+template <typename T, bool EDGE>
+__global__ __launch_bounds__(kBlock, 3) void vif_s0_mfma_kernel(const VifStatArgs a) {
   constexpr int N = 17, TW = 240, ND = 9, TH = kVifTileH;
   constexpr bool W16 = sizeof(T) == 2;
   constexpr int ES = (int)sizeof(T);
-  __shared__ __attribute__((aligned(16))) f2 sv[MOTION ? 6 : 5][TH / 2][kP2];
+  __shared__ __attribute__((aligned(16))) f2 sv[5][TH / 2][kP2];
   __shared__ __attribute__((aligned(16))) f2 sd[TH / 2][kP2];
   __shared__ double red[12];
 
@@ -533,26 +480,8 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
   h8 A[NA];
 #pragma unroll
   for (int f = 0; f < NA; ++f) A[f] = __builtin_bit_cast(h8, a.atab[kSlotFrag[f] * 64 + lane]);
-  h8 Am[2];  // motion band pieces
-  if (MOTION) {
-    Am[0] = __builtin_bit_cast(h8, a.atab[10 * 64 + lane]);
-    Am[1] = __builtin_bit_cast(h8, a.atab[11 * 64 + lane]);
-  }
-  // previous reference frame (motion): the frame before in the run, the caller's halo for the run's first frame
-  const T* __restrict__ prv = nullptr;
-  unsigned pitch_p = 0;
-  if (MOTION) {
-    if (fr == 0) { prv = (const T*)a.mprev0; pitch_p = (unsigned)a.mprev0_pitch * ES; }
-    else { prv = ref - a.frame_pitch_r; pitch_p = pitch_r; }
-  }
-  const bool have_prev = MOTION && prv != nullptr;   // workgroup-uniform
-  const auto rsrc_p = make_rsrc(have_prev ? (const void*)prv : (const void*)ref, (unsigned)a.h * (have_prev ? pitch_p : pitch_r));
-  // motion mirrors like the float extractors (fold 2n - 1) whatever border VIF uses
-  const bool same_fold = a.fold_w == 2 * a.w - 1 && a.fold_h == 2 * a.h - 1;
-
   f2 park[2][5][2];   // lower tile's rows {2g, 2g+1} of columns 2n, 2n+1 per pass and signal
   f4 park_d[2];    // lower tile's decimation row g: {ref, dis} x 2 columns
-  f4 park_m[2];    // lower tile's motion rows
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int col0 = 64 * wave + 32 * pass + 2 * n;  // tile column (= LDS column) of N-block 0; N-block 1 is col0 + 1
@@ -621,49 +550,7 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
         }
       }
     }
-    unsigned cm_[8], pm_[8];   // motion: current / previous reference rows (two columns each, as rr_)
-    if (MOTION && have_prev) {
-      if (!EDGE) {
-        const unsigned gx = (unsigned)(x0 - (N / 2) + col0);
-        const unsigned gy = (unsigned)(y0 - (N / 2) + 8 * g);
-        const unsigned off_p = gy * pitch_p + gx * ES;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          cm_[j] = rr_[j];
-          if (W16) pm_[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc_p, off_p, (unsigned)j * pitch_p, 0);
-          else pm_[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_p, off_p, (unsigned)j * pitch_p, 0);
-        }
-      } else {
-        const unsigned gx0 = (unsigned)mirror1(x0 - (N / 2) + col0, a.w) * ES;
-        const unsigned gx1 = (unsigned)mirror1(x0 - (N / 2) + col0 + 1, a.w) * ES;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned gy = (unsigned)mirror1(y0 - (N / 2) + 8 * g + j, a.h);
-          if (W16) {
-            const unsigned p0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_p, gy * pitch_p + gx0, 0, 0);
-            const unsigned p1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_p, gy * pitch_p + gx1, 0, 0);
-            pm_[j] = p0 | (p1 << 16);
-            if (same_fold) cm_[j] = rr_[j];
-            else {
-              const unsigned c0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, gy * pitch_r + gx0, 0, 0);
-              const unsigned c1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, gy * pitch_r + gx1, 0, 0);
-              cm_[j] = c0 | (c1 << 16);
-            }
-          } else {
-            const unsigned p0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_p, gy * pitch_p + gx0, 0, 0) & 0xffu;
-            const unsigned p1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_p, gy * pitch_p + gx1, 0, 0) & 0xffu;
-            pm_[j] = p0 | (p1 << 8);
-            if (same_fold) cm_[j] = rr_[j];
-            else {
-              const unsigned c0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx0, 0, 0) & 0xffu;
-              const unsigned c1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, gy * pitch_r + gx1, 0, 0) & 0xffu;
-              cm_[j] = c0 | (c1 << 8);
-            }
-          }
-        }
-      }
-    }
-    f4 D[5][2], Dd[2][2], Dm[2];
+    f4 D[5][2], Dd[2][2];
     // Accumulators start in the FIRST product of each chain (srcC = 0) instead of being cleared one by one.
     const f4 zero4 = f4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -695,21 +582,6 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
         for (int v = 0; v < 4; ++v) t[v] = f16_tiny_minus(du[v], MID_TINY);
         const h8 B = frag_from(t[0], t[1], t[2], t[3]);
         PQA_MMA0(D[1][b], MU0, zero4); PQA_MMA0(Dd[1][b], 5, zero4); PQA_MMA(D[1][b], MU1); PQA_MMA(Dd[1][b], 6); PQA_MMA(D[1][b], MU2); PQA_MMA(Dd[1][b], 7);
-      }
-      if (MOTION) {  // frame difference of the reference (exact integers, |.| <= 255 / 1023), 5-tap band, two tap pieces
-        if (have_prev) {
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const s2v cu = __builtin_bit_cast(s2v, __builtin_amdgcn_perm(cm_[2 * v + 1], cm_[2 * v], selb));
-            const s2v pu = __builtin_bit_cast(s2v, __builtin_amdgcn_perm(pm_[2 * v + 1], pm_[2 * v], selb));
-            t[v] = __builtin_bit_cast(unsigned, __builtin_convertvector(cu - pu, h2));
-          }
-          const h8 B = frag_from(t[0], t[1], t[2], t[3]);
-          Dm[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Am[0], B, zero4, 0, 0, 0);
-          Dm[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Am[1], B, Dm[b], 0, 0, 0);
-        } else {
-          Dm[b] = zero4;   // first frame of a clip: motion is 0
-        }
       }
       // squares and cross term: integer products (exact); their digits are f16 operands as they are (k * 2^-24)
 #pragma unroll
@@ -786,14 +658,10 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
       lds_store_f32(slot + 1, Dd[1][b][0]);
     }
     park_d[pass] = f4{Dd[0][0][1], Dd[1][0][1], Dd[0][1][1], Dd[1][1][1]};
-    if (MOTION) {
-      *reinterpret_cast<f4*>(&sv[5][g][col0]) = f4{Dm[0][0], Dm[0][1], Dm[1][0], Dm[1][1]};
-      park_m[pass] = f4{Dm[0][2], Dm[0][3], Dm[1][2], Dm[1][3]};
-    }
   }
   if (!skip_upper) {   // workgroup-uniform
     __syncthreads();
-    vif_hstat<N, TW, ND, !EDGE, MOTION>(a, &sv[0][0][0], &sd[0][0], red, fr, ty * a.tiles_x + tx, x0, y0);
+    vif_hstat<N, TW, ND, !EDGE>(a, &sv[0][0][0], &sd[0][0], red, fr, ty * a.tiles_x + tx, x0, y0);
     // (vif_hstat ends with a workgroup barrier inside its block sum: every LDS read of the upper tile is done)
   } else {
     __syncthreads();   // the upper tile's LDS stores above must not race with the lower tile's below
@@ -807,10 +675,9 @@ __global__ __launch_bounds__(kBlock, MOTION ? 2 : 3) void vif_s0_mfma_kernel(con
       lds_store_f2(&sv[s][g][col0 + 1], park[pass][s][1]);
     }
     *reinterpret_cast<f4*>(&sd[g][col0]) = park_d[pass];
-    if (MOTION) *reinterpret_cast<f4*>(&sv[5][g][col0]) = park_m[pass];
   }
   __syncthreads();
-  vif_hstat<N, TW, ND, !EDGE, MOTION>(a, &sv[0][0][0], &sd[0][0], red, fr, (ty + 1) * a.tiles_x + tx, x0, y0 + TH);
+  vif_hstat<N, TW, ND, !EDGE>(a, &sv[0][0][0], &sd[0][0], red, fr, (ty + 1) * a.tiles_x + tx, x0, y0 + TH);
 }
 
 // The operand encoding above leans on f16 denormals surviving v_pk_add_f16 and the MFMA's B operand.  gfx950 keeps them
@@ -836,8 +703,6 @@ __global__ void f16_tiny_probe_kernel(int* ok) {
 // registers 0 / 1 and leaves 2, 3 empty.
 static bool build_atab(uint16_t* out /* [kAtabFrags][64][8] */) {
   const Taps c17 = gaussian_taps(17), c9 = gaussian_taps(9);
-  float c5[5];
-  motion_taps(c5);
   bool exact = true;
   for (int lane = 0; lane < 64; ++lane) {
     const int m = lane & 15, gg = m >> 2, i = m & 3, kg = lane >> 4;
@@ -870,8 +735,7 @@ static bool build_atab(uint16_t* out /* [kAtabFrags][64][8] */) {
       }
       if (pieces(cd * 262144.0, 3, 5) != 0.0) exact = false;
       pieces(c * 512.0, 2, 8);
-      const int t5 = k - (row + 6);   // motion: output row y blurs input rows y + 6 .. y + 10 of the 32-row window
-      pieces((t5 >= 0 && t5 <= 4) ? (double)c5[t5] * 131072.0 : 0.0, 2, 10);
+      pieces(0.0, 2, 10);
     }
   }
   return exact;
@@ -900,18 +764,11 @@ hipError_t launch_stat_n(hipStream_t stream, Elem elem, const VifStatArgs& a, in
   return hipGetLastError();
 }
 
-// Scale 0, 8 bit: interior tile pairs on the matrix cores, border tiles on the VALU kernel (same partials, same planes).
-// Returns false when the geometry / alignment has no interior (the caller then runs the VALU kernel on every tile).
-// Returns false when nothing was launched (the caller then runs the VALU kernel on every tile).  *fused_motion tells
-// whether the launches also produced the motion partials (mo != null and the layout allowed it).
-bool launch_s0_split(hipStream_t stream, bool ten_bit, const VifStatArgs& base, int n_frames, const VifMotionFusion* mo,
-                     bool* fused_motion, hipError_t* err) {
+// Scale 0 of 8- and 10-bit clips, round-2 kernel: tile pairs through vif_s0_mfma_kernel (vertical pass on the matrix cores,
+// horizontal pass on the VALU), pairs on an image edge through its EDGE variant.  Returns false when nothing was launched
+// (no table, pitches / bases the two-column loads cannot take): the caller then runs the VALU kernel on every tile.
+bool launch_s0_split(hipStream_t stream, bool ten_bit, const VifStatArgs& base, int n_frames, hipError_t* err) {
   constexpr int TW = 240, TH = kVifTileH;
-  *fused_motion = false;
-  {  // PQA_VIF_MFMA=0: every tile on the VALU kernel (A/B measurements, and the tests that compare the two paths)
-    const char* e = getenv("PQA_VIF_MFMA");
-    if (e && e[0] == '0') return false;
-  }
   const int tiles_y = base.n_tiles / base.tiles_x, pair_rows = tiles_y / 2;
   if (pair_rows == 0) return false;
   // the interior kernel loads two columns at a time (16 bits of an 8-bit plane, 32 bits of a 10-bit plane): even element
@@ -929,23 +786,6 @@ bool launch_s0_split(hipStream_t stream, bool ten_bit, const VifStatArgs& base, 
   const float sq = ten_bit ? 2048.0f : 8192.0f, dec = ten_bit ? 16.0f : 64.0f;
   for (int k = 0; k < 17; ++k) m.taps.ht[k] = f2{base.taps.ht[k].x * sq, base.taps.ht[k].y * sq};
   for (int k = 0; k < 9; ++k) m.taps.dt[k] = f2{base.taps.dt[k].x * dec, base.taps.dt[k].y * dec};
-  // Fused motion is an OPT-IN experiment (PQA_FUSE_MOTION=1), off by default because it LOSES: measured at 2160p the
-  // scale-0 launches go from 35.3 to 47.2 us per frame to save the 5.1 us of motion_kernel (12 900 vs 14 030 frames/s).
-  // The sixth plane costs as many VALU instructions per pixel as the standalone kernel spends in total (0.26 vs 0.23
-  // wave-instructions: the MFMA replaces the vertical FMAs but the operand preparation takes their place), and its LDS
-  // takes the kernel to 2 workgroups per CU.  Kept for the measurement and its parity test, not for production.
-  bool motion = false;
-  {
-    const char* e = getenv("PQA_FUSE_MOTION");
-    motion = e && e[0] == '1' && mo != nullptr && mo->partials != nullptr;
-    if (motion && mo->prev0 && ((mo->prev0_row_pitch & 1) || ((uintptr_t)mo->prev0 & amask))) motion = false;
-  }
-  if (motion) {
-    m.mprev0 = mo->prev0; m.mprev0_pitch = mo->prev0_row_pitch; m.mpart = mo->partials;
-    float c5[5];
-    motion_taps(c5);
-    for (int k = 0; k < 5; ++k) m.mt[k] = f2{c5[k] * kMfmaMotionScale, c5[k] * kMfmaMotionScale};
-  }
   // Pair p = tiles (2p, 2p+1), rows 16p .. 16p+15; it is INTERIOR when its 32 x 256 input window (rows 16p-8 .. 16p+23,
   // columns 240tx-8 .. 240tx+247) lies inside the image: those pairs load two columns at a time with scalar row offsets.
   // An odd last tile row is produced by one more (edge) pair that starts one tile higher and skips its upper tile.
@@ -960,17 +800,15 @@ bool launch_s0_split(hipStream_t stream, bool ten_bit, const VifStatArgs& base, 
   const int n_int = (m.tx_hi - m.tx_lo) * (m.ty_hi - m.ty_lo);
   const int n_edge = base.tiles_x * m.grid_rows - n_int;
   const dim3 gi(n_int, n_frames), ge(n_edge, n_frames), block(kBlock);
-#define PQA_LAUNCH_MFMA(T, MO)                                                                         \
-  do {                                                                                                 \
-    if (n_int > 0) hipLaunchKernelGGL((vif_s0_mfma_kernel<T, false, MO>), gi, block, 0, stream, m);    \
-    if ((*err = hipGetLastError()) != hipSuccess) return true;                                         \
-    if (n_edge > 0) hipLaunchKernelGGL((vif_s0_mfma_kernel<T, true, MO>), ge, block, 0, stream, m);    \
-    *err = hipGetLastError();                                                                          \
+#define PQA_LAUNCH_MFMA(T)                                                                          \
+  do {                                                                                              \
+    if (n_int > 0) hipLaunchKernelGGL((vif_s0_mfma_kernel<T, false>), gi, block, 0, stream, m);     \
+    if ((*err = hipGetLastError()) != hipSuccess) return true;                                      \
+    if (n_edge > 0) hipLaunchKernelGGL((vif_s0_mfma_kernel<T, true>), ge, block, 0, stream, m);     \
+    *err = hipGetLastError();                                                                       \
   } while (0)
-  if (ten_bit) { if (motion) PQA_LAUNCH_MFMA(uint16_t, true); else PQA_LAUNCH_MFMA(uint16_t, false); }
-  else { if (motion) PQA_LAUNCH_MFMA(uint8_t, true); else PQA_LAUNCH_MFMA(uint8_t, false); }
+  if (ten_bit) PQA_LAUNCH_MFMA(uint16_t); else PQA_LAUNCH_MFMA(uint8_t);
 #undef PQA_LAUNCH_MFMA
-  *fused_motion = motion;
   return true;
 }
 
@@ -1025,9 +863,15 @@ hipError_t vif_mfma_prepare() {
 
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                            int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
-                           MutPlaneRun next_ref, MutPlaneRun next_dis, const VifMotionFusion* motion, bool* fused_motion) {
-  if (fused_motion) *fused_motion = false;
+                           MutPlaneRun next_ref, MutPlaneRun next_dis, int s0_mode, int* n_partials) {
+  if (n_partials) *n_partials = vif_tiles_x(scale, w) * vif_tiles_y(h);
   if (n_frames <= 0) return hipSuccess;
+  if (scale == 0 && elem == ELEM_U8 && s0_mode == VIF_S0_AUTO && next_ref.base && next_dis.base) {
+    hipError_t err = hipSuccess;
+    if (launch_vif_s0_march(stream, ref, dis, n_frames, w, h, gain_limit, border101, partials, next_ref, next_dis, n_partials, &err))
+      return err;
+    if (n_partials) *n_partials = vif_tiles_x(scale, w) * vif_tiles_y(h);
+  }
   VifStatArgs a{};
   a.ref = ref.base; a.dis = dis.base;
   a.row_pitch_r = ref.row_pitch; a.frame_pitch_r = ref.frame_pitch;
@@ -1045,15 +889,11 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
   const Taps nxt = scale < 3 ? gaussian_taps(kVifN[scale + 1]) : Taps{};
   a.taps = tap_pairs(cur, kVifN[scale], scale < 3 ? &nxt : nullptr, scale < 3 ? kVifN[scale + 1] : 0);
   if (scale < 3 && (!a.dst_ref || !a.dst_dis)) return hipErrorInvalidValue;
-  // scale 0 of 8-bit and 10-bit clips: vertical pass on the matrix cores (10 bit is recognised by its sample scale 1/4;
-  // 12-bit clips and every deeper scale run the VALU kernel)
-  if (scale == 0 && (elem == ELEM_U8 || (elem == ELEM_U16 && inv_scale == 0.25f))) {
+  // scale 0 of 10-bit clips (and of 8-bit clips the march kernel could not take, or with VIF_S0_SPLIT): vertical pass on
+  // the matrix cores (10 bit is recognised by its sample scale 1/4; 12-bit clips and every deeper scale run the VALU kernel)
+  if (scale == 0 && s0_mode != VIF_S0_VALU && (elem == ELEM_U8 || (elem == ELEM_U16 && inv_scale == 0.25f))) {
     hipError_t err = hipSuccess;
-    bool fused = false;
-    if (launch_s0_split(stream, elem == ELEM_U16, a, n_frames, motion, &fused, &err)) {
-      if (fused_motion) *fused_motion = fused;
-      return err;
-    }
+    if (launch_s0_split(stream, elem == ELEM_U16, a, n_frames, &err)) return err;
   }
   switch (scale) {
     case 0: return launch_stat_n<17, 240, 9>(stream, elem, a, n_frames);

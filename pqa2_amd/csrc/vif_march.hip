@@ -1,0 +1,483 @@
+// VIF scale 0 with BOTH filter passes on the f16 matrix cores, no LDS, no workgroup barriers ("march" kernel).
+//
+// Arithmetic: libvmaf's float extractor (vif.c compute_vif, vif_tools.c vif_filter1d_s / _sq_s / _xy_s, vif_dec2_s,
+// vif_statistic_s) -- the code behind the reference's `libvmaf=` call site, app/vmaf_analyzer.py:373-419 -- restated
+// in oracle/vmaf_oracle.c.  The separable 17-tap filter commutes, so the HORIZONTAL pass runs first here.
+//
+// Why.  vif_s0_mfma_kernel (vif.hip) put the vertical pass on the matrix pipe and left the horizontal pass as 340 packed
+// FP32 FMAs per wave and tile, 45 % of its VALU issue, with the two passes meeting in LDS (24-27 % bank conflicts on its
+// 8-byte accumulator stores, two barriers per tile pair).  Here the second pass is an MFMA as well, and its operand comes
+// straight out of the first pass's accumulators:
+//
+//   pass 1 (exact):  D1[row][out col] = sum_k  X[row][in col k] * T1[k][out col]      X = integer digit planes (A operand)
+//   pass 2:          D2[col][out row] = sum_k  P[col][in row k] * T2[k][out row]      P = D1 split into two f16 pieces
+//
+// v_mfma_f32_16x16x32_f16 keeps D[m][n] of lane l = (n = l & 15, m = 4 (l >> 4) + i): four ROWS of one column after pass 1.
+// The A operand of pass 2 wants, from the same lane, eight K elements of row m = l & 15 -- and K may be enumerated in any
+// order as long as the tap matrix T2 uses the same one.  So K group (l >> 4) of pass 2 is DEFINED as {rows 4 (l >> 4) + i of
+// the previous 16-row block, rows 4 (l >> 4) + i of the current one}: the lane's own accumulators, converted, ARE its operand.
+// No transposition, no LDS, no cross-lane traffic; a wave is independent of every other wave.
+//
+// A wave owns a 16-column stripe and MARCHES down it in 16-row blocks: load 16 x 32 samples (one 8-byte load per lane and
+// image), pass 1, split, pass 2 against the previous block's pieces, statistic on the 16 x 16 outputs, next block.  The
+// 32-row window of the vertical filter is the pair (previous block, current block), so the only redundant work is the first
+// block of a segment ((L + 1) / L on pass 1 for a segment of L blocks).
+//
+// Pass 1 is exact exactly as in vif_s0_mfma_kernel: the five signals r', d', r'^2, d'^2, r'd' (r' = r - 128) enter as
+// base-256 digit planes whose 16-bit patterns are their own f16 encodings (k * 2^-24), every f32 tap is split into three
+// f16 pieces without loss, products are exact in f32 and the accumulator is f32.
+// Pass 2 splits each f32 result v into hi = f16(v), lo = f16(v - hi) (both round-to-nearest: |v - hi - lo| <= 2^-23 |v|, the
+// size of ONE f32 rounding) and each tap c * 2^8 into c1 = f16(.), c2 = f16(. - c1); it accumulates hi c1 + hi c2 + lo c1 in
+// f32 (the dropped lo c2 is below 2^-24 of the term).  That is an f32-grade evaluation in a different rounding order, not a
+// reduced-precision one: tools/sim_split_horizontal.py measured the same distance from an f64 evaluation as an all-f32
+// pass in libvmaf's order (8e-8 on the scale-0 numerator), tests/test_gpu_*.py hold it to the same bars as before.
+//
+// Units.  Pass 2's taps carry 2^8 (so that c2 is a normal f16), the means enter it as natural / 16 and the squares as
+// natural: the means come out times 16 and the squares times 256, i.e. everything is consistently in units U = 16: the
+// statistic runs on those numbers with sigma_nsq, eps and 1 / sigma_max scaled by 256 (g and both log arguments are
+// scale-free), no rescaling instruction anywhere.
+//
+// The next scale's input (9-tap filter, even rows and columns: vif_dec2_s) rides along: pass 1 puts the eight even output
+// columns of ref and of dis into ONE accumulator (tap matrices that are zero on the other image's eight N slots), pass 2
+// produces the eight even rows; lanes 0..7 of each 16-lane row then hold four consecutive samples of a half-resolution row
+// and store them as one 16-byte write.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "kernels.h"
+#include "pqa_device.h"
+
+namespace pqa {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef short s2v __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+// fragments of the per-lane tap table (each: 64 lanes x 8 f16)
+enum : int {
+  F_HI = 0,    // 0..2   pass 1, c * 2^19 in three pieces (digits that weigh 2^8)
+  F_LO = 3,    // 3..5   pass 1, c * 2^11 in three pieces (means: all three; low digits: the first two)
+  F_DR = 6,    // 6..8   pass 1, next scale's taps c' * 2^18, even output columns of REF in N slots 0..7
+  F_DD = 9,    // 9..11  the same for DIS in N slots 8..15
+  F_V = 12,    // 12,13  pass 2, c * 2^8 in two pieces, K order {previous block rows, current block rows}
+  F_VD = 14,   // 14,15  pass 2 of the next scale's input, c' * 2^8, even output rows in N slots 0..7
+  kMarchFrags = 16
+};
+
+struct MarchArgs {
+  const void* ref;
+  const void* dis;
+  unsigned pitch_r, pitch_d;               // bytes
+  int64_t frame_pitch_r, frame_pitch_d;    // bytes
+  int w, h, fold_w, fold_h;
+  int aligned;                             // bases and pitches allow 8-byte loads
+  float gain_limit;
+  double* partials;                        // [n_frames][n_part][2]
+  int n_part;
+  float* dst_ref;
+  float* dst_dis;
+  unsigned dst_pitch_r, dst_pitch_d;       // floats
+  int64_t dst_frame_pitch_r, dst_frame_pitch_d;
+  int n_cb, n_cbg, seg_blocks, n_seg, row_blocks;
+  const uint4* tab;
+};
+
+__device__ __forceinline__ h8 frag4(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return __builtin_bit_cast(h8, u4v{a, b, c, d});
+}
+// two integers k < 2048 (one per 16-bit half) -> two f16 (k - off) * 2^-24, exact; off_bits = off as f16 bits | 0x8000
+__device__ __forceinline__ unsigned tiny_minus(unsigned x, unsigned short off_bits) {
+  const h2 o = __builtin_bit_cast(h2, (unsigned)off_bits | ((unsigned)off_bits << 16));
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, x) + o);
+}
+__device__ __forceinline__ f4 mma(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// Four f32 values (scaled by `s`, an exact power of two) -> two f16 pieces each: hi = rne(v), lo = rne(v - hi).
+// hi / lo: {piece(v0), piece(v1)}, {piece(v2), piece(v3)} -- the element order of an MFMA operand.
+__device__ __forceinline__ void split4(const f4 v, const float s, unsigned (&hi)[2], unsigned (&lo)[2]) {
+  const f2 a = f2{v[0], v[1]} * f2{s, s}, b = f2{v[2], v[3]} * f2{s, s};
+  const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
+  // v - hi is exact in f32 (hi shares v's leading bits); written as fma so that the f16 operand feeds v_fma_mix_f32
+  const f2 ra = f2{__builtin_fmaf((float)ha[0], -1.0f, a[0]), __builtin_fmaf((float)ha[1], -1.0f, a[1])};
+  const f2 rb = f2{__builtin_fmaf((float)hb[0], -1.0f, b[0]), __builtin_fmaf((float)hb[1], -1.0f, b[1])};
+  hi[0] = __builtin_bit_cast(unsigned, ha);
+  hi[1] = __builtin_bit_cast(unsigned, hb);
+  lo[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, h2));
+  lo[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(rb, h2));
+}
+
+struct Pieces {          // one 16-row block after pass 1: rows 4 (lane >> 4) + i of column (lane & 15)
+  unsigned hi[5][2], lo[5][2];
+  unsigned dhi[2], dlo[2];   // next scale's input: N slot (lane & 15) = even column of ref (0..7) / dis (8..15)
+};
+
+// vif_statistic_s on two horizontally adjacent pixels, in units U = 16 (see the file comment): accumulates the low-branch
+// sums and the three log products.  Same algebra as vif_hstat (vif.hip), which documents each override that drops out.
+struct StatAcc {
+  f2 num2, den2, pn, qn, pd;
+};
+__device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2, const f2 xx, const f2 yy, const f2 xy,
+                                          const bool v0, const bool v1, const float gain_limit) {
+  const float sigma_nsq = 2.0f * 256.0f, eps = 1.0e-10f * 256.0f, sigma_max_inv = 4.0f / (255.0f * 255.0f * 256.0f);
+  const f2 s1 = xx - mu1 * mu1;
+  f2 s2 = yy - mu2 * mu2;
+  const f2 s12 = xy - mu1 * mu2;
+  s2 = f2{fmaxf(s2.x, 0.0f), fmaxf(s2.y, 0.0f)};
+  const bool hx = v0 && !(s1.x < sigma_nsq), hy = v1 && !(s1.y < sigma_nsq);
+  const bool lx = v0 && (s1.x < sigma_nsq), ly = v1 && (s1.y < sigma_nsq);
+  const f2 s1h = f2{hx ? s1.x : 0.0f, hy ? s1.y : 0.0f};
+  const f2 gden = s1h + f2{eps, eps};
+  const f2 grcp = f2{fast_rcp(gden.x), fast_rcp(gden.y)};
+  f2 g = s12 * grcp;
+  g = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, gden, s12), grcp, g);
+  f2 sv = s2 - g * s12;
+  sv = f2{fmaxf(sv.x, eps), fmaxf(sv.y, eps)};
+  g = f2{__builtin_amdgcn_fmed3f(g.x, 0.0f, gain_limit), __builtin_amdgcn_fmed3f(g.y, 0.0f, gain_limit)};
+  const f2 svn = sv + f2{sigma_nsq, sigma_nsq};
+  const f2 narg = __builtin_elementwise_fma(g * g, s1h, svn);
+  const f2 darg = __builtin_elementwise_fma(s1h, f2{1.0f / sigma_nsq, 1.0f / sigma_nsq}, f2{1.0f, 1.0f});
+  const f2 low = __builtin_elementwise_fma(s2, f2{-sigma_max_inv, -sigma_max_inv}, f2{1.0f, 1.0f});
+  s.pn *= narg;
+  s.qn *= svn;
+  s.pd *= darg;
+  const f2 wl = f2{lx ? 1.0f : 0.0f, ly ? 1.0f : 0.0f};
+  s.num2 = __builtin_elementwise_fma(wl, low, s.num2);
+  s.den2 += wl;
+}
+
+__global__ __launch_bounds__(kBlock, 2) void vif_s0_march_kernel(const MarchArgs a) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int id = xcd_remap(blockIdx.x, a.n_cbg * a.n_seg);
+  const int cbg = id % a.n_cbg, seg = id / a.n_cbg;
+  const int cb = cbg * 4 + wave;   // this wave's 16-column stripe
+  const int fr = blockIdx.y;
+  double* part = a.partials + ((int64_t)fr * a.n_part + (int64_t)(seg * a.n_cbg + cbg) * 4 + wave) * 2;
+  if (cb >= a.n_cb) {   // wave-uniform: the last workgroup of a row of stripes may have idle waves; their slots read 0
+    if (lane == 0) { part[0] = 0.0; part[1] = 0.0; }
+    return;
+  }
+  const int x0 = cb * 16;
+  const int rb0 = seg * a.seg_blocks;
+  const int n_out = min(a.seg_blocks, a.row_blocks - rb0);   // 16-row output blocks of this segment (>= 1)
+  const int ys = rb0 * 16;
+  const int m = lane & 15, kq = lane >> 4;
+
+  const uint8_t* __restrict__ ref = (const uint8_t*)a.ref + (int64_t)fr * a.frame_pitch_r;
+  const uint8_t* __restrict__ dis = (const uint8_t*)a.dis + (int64_t)fr * a.frame_pitch_d;
+  const auto rsrc_r = make_rsrc(ref, (unsigned)a.h * a.pitch_r);
+  const auto rsrc_d = make_rsrc(dis, (unsigned)a.h * a.pitch_d);
+  // all 32 input columns of the stripe inside the image and 8-byte loads allowed: one load per lane and image
+  const bool colfast = a.aligned && x0 - 8 >= 0 && x0 + 24 <= a.w;   // wave-uniform
+  const int xin = x0 - 8 + 8 * kq;                                    // this lane's first input column
+
+  // tap-matrix fragments of this lane
+  h8 T[kMarchFrags];
+#pragma unroll
+  for (int f = 0; f < kMarchFrags; ++f) T[f] = __builtin_bit_cast(h8, a.tab[f * 64 + lane]);
+
+  // ---- loads: 8 consecutive samples of row (block row m) per image ----------------------------------------------
+  const auto load_block = [&](int rb, u2v& R, u2v& D) {
+    const int yin = ys - 8 + 16 * rb + m;
+    const unsigned my = (unsigned)mirror_fold(yin, a.h, a.fold_h);
+    if (colfast) {
+      R = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, my * a.pitch_r + (unsigned)xin, 0, 0));
+      D = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, my * a.pitch_d + (unsigned)xin, 0, 0));
+    } else {   // stripes at the left / right image edge (mirrored columns) or unaligned planes: byte by byte
+      unsigned r[8], d[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned mx = (unsigned)mirror_fold(xin + j, a.w, a.fold_w);
+        r[j] = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, my * a.pitch_r + mx, 0, 0) & 0xffu;
+        d[j] = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, my * a.pitch_d + mx, 0, 0) & 0xffu;
+      }
+      R = u2v{r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24)};
+      D = u2v{d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24), d[4] | (d[5] << 8) | (d[6] << 16) | (d[7] << 24)};
+    }
+  };
+
+  // ---- pass 1 + split: one 16 x 32 input block -> this lane's pieces -----------------------------------------------
+  const auto pass1 = [&](const u2v R, const u2v D, Pieces& P) {
+    const f4 z = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    // 16-bit lanes {col 2v, col 2v+1} of this lane's 8 columns: byte -> zero-extended half (one v_perm_b32 each)
+    unsigned ru[4], du[4], r16[4], d16[4], t[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const unsigned sel = (v & 1) ? 0x0c030c02u : 0x0c010c00u;
+      ru[v] = __builtin_amdgcn_perm(0u, R[v >> 1], sel);
+      du[v] = __builtin_amdgcn_perm(0u, D[v >> 1], sel);
+      r16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, ru[v]) - s2v{128, 128});
+      d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{128, 128});
+    }
+    f4 Dh[5], Dd;
+    {  // means r' and d' = (sample - 128) * 2^-24, and the next scale's input from the same operands
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t[v] = tiny_minus(ru[v], 0x8080);
+      const h8 A = frag4(t[0], t[1], t[2], t[3]);
+      Dh[0] = mma(A, T[F_LO], z); Dd = mma(A, T[F_DR], z);
+      Dh[0] = mma(A, T[F_LO + 1], Dh[0]); Dd = mma(A, T[F_DR + 1], Dd);
+      Dh[0] = mma(A, T[F_LO + 2], Dh[0]); Dd = mma(A, T[F_DR + 2], Dd);
+    }
+    {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t[v] = tiny_minus(du[v], 0x8080);
+      const h8 A = frag4(t[0], t[1], t[2], t[3]);
+      Dh[1] = mma(A, T[F_LO], z); Dd = mma(A, T[F_DD], Dd);
+      Dh[1] = mma(A, T[F_LO + 1], Dh[1]); Dd = mma(A, T[F_DD + 1], Dd);
+      Dh[1] = mma(A, T[F_LO + 2], Dh[1]); Dd = mma(A, T[F_DD + 2], Dd);
+    }
+#pragma unroll
+    for (int s = 2; s < 5; ++s) {   // r'^2, d'^2, r'd': exact 16-bit integer products, digits base 256
+      unsigned q[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const s2v x = __builtin_bit_cast(s2v, s == 3 ? d16[v] : r16[v]);
+        const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
+        // the cross term is signed: + 64 * 256 makes both digits unsigned (one v_pk_mad_u16), the 64 comes off below
+        q[v] = __builtin_bit_cast(unsigned, s == 4 ? (s2v)(x * y + s2v{0x4000, 0x4000}) : (s2v)(x * y));
+      }
+      {  // low digit: byte 0 of each 16-bit product
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t[v] = __builtin_amdgcn_perm(0u, q[v], 0x0c020c00u);
+        const h8 A = frag4(t[0], t[1], t[2], t[3]);
+        Dh[s] = mma(A, T[F_LO], z);
+        Dh[s] = mma(A, T[F_LO + 1], Dh[s]);
+      }
+      {  // high digit: byte 1
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          t[v] = __builtin_amdgcn_perm(0u, q[v], 0x0c030c01u);
+          if (s == 4) t[v] = tiny_minus(t[v], 0x8040);   // - 64 * 2^-24
+        }
+        const h8 A = frag4(t[0], t[1], t[2], t[3]);
+        Dh[s] = mma(A, T[F_HI], Dh[s]);
+        Dh[s] = mma(A, T[F_HI + 1], Dh[s]);
+        Dh[s] = mma(A, T[F_HI + 2], Dh[s]);
+      }
+    }
+    // pass 1 leaves every signal times 2^-13 and the next scale's input times 2^-6 (operands k * 2^-24, pieces of
+    // c * 2^11, c * 2^19 on the digits that weigh 2^8, c' * 2^18).  Into pass 2: means as natural / 16, squares as natural,
+    // the next scale's input as natural.
+    split4(Dh[0], 512.0f, P.hi[0], P.lo[0]);
+    split4(Dh[1], 512.0f, P.hi[1], P.lo[1]);
+    split4(Dh[2], 8192.0f, P.hi[2], P.lo[2]);
+    split4(Dh[3], 8192.0f, P.hi[3], P.lo[3]);
+    split4(Dh[4], 8192.0f, P.hi[4], P.lo[4]);
+    split4(Dd, 64.0f, P.dhi, P.dlo);
+  };
+
+  double dnum = 0.0, dden = 0.0;
+  // validity of this lane's four output columns (wave-uniform per K group, constant over the march)
+  bool vcol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vcol[i] = x0 + 4 * kq + i < a.w;
+  const int ow = a.w >> 1, oh = a.h >> 1;
+
+  Pieces prev, cur;
+  u2v Rn, Dn;
+  load_block(0, Rn, Dn);
+  for (int rb = 0; rb <= n_out; ++rb) {
+    const u2v Rc = Rn, Dc = Dn;
+    if (rb < n_out) load_block(rb + 1, Rn, Dn);   // in flight while this block is computed
+    pass1(Rc, Dc, cur);
+    if (rb > 0) {
+      // ---- pass 2: window = (previous block, current block); out rows yo .. yo + 15, this lane: row yo + m, cols 4 kq + i
+      const int yo = ys + 16 * (rb - 1);
+      const f4 z = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      f4 V[5];
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const h8 Ah = frag4(prev.hi[s][0], prev.hi[s][1], cur.hi[s][0], cur.hi[s][1]);
+        const h8 Al = frag4(prev.lo[s][0], prev.lo[s][1], cur.lo[s][0], cur.lo[s][1]);
+        V[s] = mma(Ah, T[F_V], z);
+        V[s] = mma(Ah, T[F_V + 1], V[s]);
+        V[s] = mma(Al, T[F_V], V[s]);
+      }
+      f4 Vd;
+      {
+        const h8 Ah = frag4(prev.dhi[0], prev.dhi[1], cur.dhi[0], cur.dhi[1]);
+        const h8 Al = frag4(prev.dlo[0], prev.dlo[1], cur.dlo[0], cur.dlo[1]);
+        Vd = mma(Ah, T[F_VD], z);
+        Vd = mma(Ah, T[F_VD + 1], Vd);
+        Vd = mma(Al, T[F_VD], Vd);
+      }
+      // ---- next scale's input: lanes m < 8 hold 4 consecutive samples of half-resolution row yo / 2 + m --------------
+      if (m < 8) {
+        const int orow = (yo >> 1) + m, oc = (x0 >> 1) + 4 * (kq & 1);
+        if (orow < oh && oc < ow) {
+          float* __restrict__ dst = kq < 2 ? a.dst_ref + (int64_t)fr * a.dst_frame_pitch_r + (int64_t)orow * a.dst_pitch_r + oc
+                                           : a.dst_dis + (int64_t)fr * a.dst_frame_pitch_d + (int64_t)orow * a.dst_pitch_d + oc;
+          const f4 o = Vd * f4{1.0f / 256.0f, 1.0f / 256.0f, 1.0f / 256.0f, 1.0f / 256.0f};
+          if (oc + 4 <= ow) {
+            *reinterpret_cast<f4*>(dst) = o;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (oc + i < ow) dst[i] = o[i];
+          }
+        }
+      }
+      // ---- statistic on this lane's 4 pixels --------------------------------------------------------------------------
+      const bool vrow = yo + m < a.h;
+      StatAcc st{f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}};
+      stat_pair(st, f2{V[0][0], V[0][1]}, f2{V[1][0], V[1][1]}, f2{V[2][0], V[2][1]}, f2{V[3][0], V[3][1]},
+                f2{V[4][0], V[4][1]}, vrow && vcol[0], vrow && vcol[1], a.gain_limit);
+      stat_pair(st, f2{V[0][2], V[0][3]}, f2{V[1][2], V[1][3]}, f2{V[2][2], V[2][3]}, f2{V[3][2], V[3][3]},
+                f2{V[4][2], V[4][3]}, vrow && vcol[2], vrow && vcol[3], a.gain_limit);
+      const float num = (st.num2.x + st.num2.y) + ((fast_log2(st.pn.x) - fast_log2(st.qn.x)) + (fast_log2(st.pn.y) - fast_log2(st.qn.y)));
+      const float den = (st.den2.x + st.den2.y) + (fast_log2(st.pd.x) + fast_log2(st.pd.y));
+      dnum += (double)num;
+      dden += (double)den;
+    }
+    prev = cur;
+  }
+  dnum = wave_sum(dnum);
+  dden = wave_sum(dden);
+  if (lane == 0) { part[0] = dnum; part[1] = dden; }
+}
+
+// ---- host: the per-lane tap-matrix fragments ------------------------------------------------------------------------
+void gaussian(int n, float* out) {   // N taps, sigma = N / 5, normalised in double, stored as float (vif_filter1d_table)
+  double v[17], sum = 0.0;
+  const double sigma = n / 5.0;
+  for (int k = 0; k < n; ++k) {
+    const double d = k - n / 2;
+    v[k] = exp(-0.5 * d * d / (sigma * sigma));
+    sum += v[k];
+  }
+  for (int k = 0; k < n; ++k) out[k] = (float)(v[k] / sum);
+}
+
+// x -> n f16 pieces (round to nearest each time); returns what is left
+double pieces(double x, int n, uint16_t* out /* stride: one fragment */, size_t stride) {
+  double r = x;
+  for (int p = 0; p < n; ++p) {
+    const _Float16 hh = (_Float16)r;
+    uint16_t bits;
+    memcpy(&bits, &hh, 2);
+    out[(size_t)p * stride] = bits;
+    r -= (double)hh;
+  }
+  return r;
+}
+
+bool build_table(uint16_t* out /* [kMarchFrags][64][8] */) {
+  float c17[17], c9[9];
+  gaussian(17, c17);
+  gaussian(9, c9);
+  bool exact = true;
+  const size_t stride = 64 * 8;
+  for (int lane = 0; lane < 64; ++lane) {
+    const int n = lane & 15, kb = lane >> 4;
+    for (int j = 0; j < 8; ++j) {
+      uint16_t* o = out + (size_t)lane * 8 + j;
+      // pass 1 (B operand): K element j of group kb = window column wc; N slot n = output column n, window column n + 8
+      const int wc = 8 * kb + j;
+      const int t = wc - n;
+      const double c = (t >= 0 && t <= 16) ? (double)c17[t] : 0.0;
+      if (pieces(c * 524288.0, 3, o + F_HI * stride, stride) != 0.0) exact = false;
+      if (pieces(c * 2048.0, 3, o + F_LO * stride, stride) != 0.0) exact = false;
+      // next scale: N slot n = even column 2 (n & 7) (window column 2 (n & 7) + 8) of ref (n < 8) or dis (n >= 8)
+      const int t9 = wc - (2 * (n & 7) + 4);
+      const double cd = (t9 >= 0 && t9 <= 8) ? (double)c9[t9] : 0.0;
+      if (pieces(n < 8 ? cd * 262144.0 : 0.0, 3, o + F_DR * stride, stride) != 0.0) exact = false;
+      if (pieces(n >= 8 ? cd * 262144.0 : 0.0, 3, o + F_DD * stride, stride) != 0.0) exact = false;
+      // pass 2 (B operand): K element j of group kb = window row 4 kb + j of the previous block (j < 4) or
+      // 16 + 4 kb + (j - 4) of the current one; N slot n = output row n, window row n + 8
+      const int wr = j < 4 ? 4 * kb + j : 16 + 4 * kb + (j - 4);
+      const int tv = wr - n;
+      pieces((tv >= 0 && tv <= 16) ? (double)c17[tv] * 256.0 : 0.0, 2, o + F_V * stride, stride);
+      const int tv9 = wr - (2 * n + 4);   // N slot n < 8 = even output row 2 n
+      pieces((n < 8 && tv9 >= 0 && tv9 <= 8) ? (double)c9[tv9] * 256.0 : 0.0, 2, o + F_VD * stride, stride);
+    }
+  }
+  return exact;
+}
+
+std::mutex g_tab_mu;
+const uint4* g_tab[64] = {};
+
+const uint4* device_tab() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_tab_mu);
+  return g_tab[dev];
+}
+
+constexpr int kMinSegBlocks = 8;   // a segment repeats one block of pass 1: (L + 1) / L
+
+}  // namespace
+
+int vif_march_partials_max(int w, int h) {
+  const int n_cbg = ((w + 15) / 16 + 3) / 4, row_blocks = (h + 15) / 16;
+  return n_cbg * 4 * ((row_blocks + kMinSegBlocks - 1) / kMinSegBlocks);
+}
+
+hipError_t vif_march_prepare() {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipSuccess;
+  std::lock_guard<std::mutex> lock(g_tab_mu);
+  if (g_tab[dev]) return hipSuccess;
+  std::vector<uint16_t> h((size_t)kMarchFrags * 64 * 8);
+  if (!build_table(h.data())) return hipSuccess;   // a tap that does not split exactly: the older kernels stay in charge
+  void* d = nullptr;
+  if ((e = hipMalloc(&d, h.size() * 2)) != hipSuccess) return e;
+  if ((e = hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) {
+    (void)hipFree(d);
+    return e;
+  }
+  g_tab[dev] = (const uint4*)d;   // lives as long as the process (16 KB per device)
+  return hipSuccess;
+}
+
+bool launch_vif_s0_march(hipStream_t stream, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
+                         int border101, double* partials, MutPlaneRun next_ref, MutPlaneRun next_dis, int* n_partials,
+                         hipError_t* err) {
+  MarchArgs a{};
+  a.tab = device_tab();
+  if (!a.tab) return false;
+  if (ref.row_pitch >= (1ll << 31) || dis.row_pitch >= (1ll << 31)) return false;
+  a.ref = ref.base; a.dis = dis.base;
+  a.pitch_r = (unsigned)ref.row_pitch; a.pitch_d = (unsigned)dis.row_pitch;
+  a.frame_pitch_r = ref.frame_pitch; a.frame_pitch_d = dis.frame_pitch;
+  a.w = w; a.h = h;
+  a.fold_w = 2 * w - (border101 ? 2 : 1); a.fold_h = 2 * h - (border101 ? 2 : 1);
+  a.aligned = (((uintptr_t)ref.base | (uintptr_t)dis.base | (uintptr_t)ref.row_pitch | (uintptr_t)dis.row_pitch |
+                (uintptr_t)ref.frame_pitch | (uintptr_t)dis.frame_pitch) & 7) == 0;
+  a.gain_limit = gain_limit;
+  a.partials = partials;
+  a.dst_ref = (float*)next_ref.base; a.dst_dis = (float*)next_dis.base;
+  a.dst_pitch_r = (unsigned)next_ref.row_pitch; a.dst_pitch_d = (unsigned)next_dis.row_pitch;
+  a.dst_frame_pitch_r = next_ref.frame_pitch; a.dst_frame_pitch_d = next_dis.frame_pitch;
+  // 16-byte stores of the half-resolution rows: pitches and bases the library allocates itself satisfy this
+  if (((uintptr_t)a.dst_ref | (uintptr_t)a.dst_dis) & 15 || (a.dst_pitch_r | a.dst_pitch_d) & 3 ||
+      (a.dst_frame_pitch_r | a.dst_frame_pitch_d) & 3)
+    return false;
+  a.n_cb = (w + 15) / 16;
+  a.n_cbg = (a.n_cb + 3) / 4;
+  a.row_blocks = (h + 15) / 16;
+  // segment length: long enough that the repeated first block is cheap, short enough that a launch has several waves
+  // per SIMD slot to balance (2 048 wave slots at two waves per SIMD)
+  int seg = a.row_blocks;
+  const long long want_waves = 6 * 2048;
+  while (seg > kMinSegBlocks && (long long)a.n_cbg * 4 * ((a.row_blocks + seg - 1) / seg) * n_frames < want_waves) seg = (seg + 1) / 2;
+  if (seg < kMinSegBlocks) seg = a.row_blocks < kMinSegBlocks ? a.row_blocks : kMinSegBlocks;
+  a.seg_blocks = seg;
+  a.n_seg = (a.row_blocks + seg - 1) / seg;
+  a.n_part = a.n_cbg * 4 * a.n_seg;
+  if (n_partials) *n_partials = a.n_part;
+  hipLaunchKernelGGL(vif_s0_march_kernel, dim3(a.n_cbg * a.n_seg, n_frames), dim3(kBlock), 0, stream, a);
+  *err = hipGetLastError();
+  return true;
+}
+
+}  // namespace pqa

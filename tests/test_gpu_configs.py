@@ -348,11 +348,12 @@ def test_rccl_gather_of_device_records_with_one_rank(tmp_path):
 @pytest.mark.parametrize("w,h,bpc", [(488, 40, 8), (489, 41, 8), (736, 48, 8), (1000, 200, 8), (1281, 721, 8), (1920, 1080, 8),
                                      (64, 48, 10), (489, 41, 10), (1000, 200, 10), (1920, 1080, 10)])
 def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
-    """8-bit scale 0 runs its interior tiles through f16 MFMA (exact integer digit planes x three-piece taps) and the
-    border tiles through the VALU kernel.  Geometries from the smallest that has ONE interior tile pair (488 x 40) up
-    to 1080p, odd sizes included.  The two paths must agree far inside the oracle bar (the digit split is exact; only
-    the f32 accumulation order differs), PQA_VIF_MFMA=0 must really switch the path off, and a caller pitch the 16-bit
-    loads cannot take (odd) must fall back without a difference in results."""
+    """Scale 0 on the matrix cores against the VALU kernel and the oracle.  8 bit: the march kernel (vif_march.hip: first
+    pass on exact integer digit planes x three-piece taps, second pass on two-piece f16 splits of the f32 intermediates);
+    10 bit: the round-2 kernel (vertical pass on the matrix cores).  Geometries from 64 x 48 up to 1080p, odd sizes
+    included.  The paths must agree far inside the oracle bar, PQA_VIF_MFMA=0 (read at pqa_create) must really switch the
+    path off, PQA_VIF_MFMA=2 must give the round-2 kernel, and a caller pitch the wide loads cannot take (odd) must not
+    change a bit: the march kernel then loads byte by byte, the round-2 kernel hands over to the VALU kernel."""
     import os
     import torch
     from pqa2_amd import synth
@@ -381,6 +382,8 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
         os.environ["PQA_VIF_MFMA"] = "0"
         valu = run()
         valu101 = run(vif_border=N.VIF_BORDER_INTEGER)
+        os.environ["PQA_VIF_MFMA"] = "2"
+        split = run()
     finally:
         if old is None:
             os.environ.pop("PQA_VIF_MFMA", None)
@@ -390,6 +393,9 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
     rel = np.abs(mfma - valu) / np.abs(valu)
     assert rel.max() < 2e-6, rel.max()
     assert (np.abs(mfma101 - valu101) / np.abs(valu101)).max() < 2e-6
+    assert (np.abs(split - valu) / np.abs(valu)).max() < 2e-6
+    if bpc == 8 and w >= 488 and h >= 40:    # the round-2 kernel is a different kernel from the march kernel (and needs one interior pair)
+        assert not np.array_equal(split.view(np.uint64), mfma.view(np.uint64))
     assert np.all(np.isfinite(mfma))
     exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc)[:, :8]
     assert (np.abs(mfma - exp) / np.abs(exp)).max() < REL_TOL
@@ -406,44 +412,7 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
         with FeatureEngine(w, h, bit_depth=bpc, features=N.FEAT_VIF) as eng:
             eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [pitch * es], [pitch * h * es])
             odd = eng.collect(0, n)[:, :8]
-        assert np.array_equal(odd.view(np.uint64), valu.view(np.uint64))
-
-
-@pytest.mark.parametrize("w,h,bpc,border", [(640, 360, 8, 0), (641, 363, 8, 1), (1000, 200, 10, 1), (1920, 1080, 8, 1)])
-def test_fused_motion_experiment_matches_the_motion_kernel(oracle32, w, h, bpc, border):
-    """PQA_FUSE_MOTION=1 (opt-in; slower): motion as a sixth plane of the matrix-core VIF kernel --
-    exact integer frame difference, 5-tap band on MFMA, horizontal blur + |.| sum in the VIF tile loop.  Same values as the
-    standalone motion kernel up to summation order (1e-6 relative), inside the oracle bar, 0 for the first frame and across
-    batch seams with the one-frame halo; every other feature bit-identical to the unfused run."""
-    import os
-    from pqa2_amd import synth
-    from pqa2_amd.engine import FeatureEngine
-    if os.environ.get("PQA_VIF_MFMA", "1") == "0":
-        pytest.skip("the matrix-core kernel is switched off in this environment: nothing to fuse motion into")
-    n = 5
-    refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
-
-    def run(fuse):
-        old = os.environ.get("PQA_FUSE_MOTION")
-        os.environ["PQA_FUSE_MOTION"] = fuse
-        try:
-            with FeatureEngine(w, h, bit_depth=bpc, vif_border=border, max_batch=2) as eng:   # 3 batches: halo carried twice
-                for i in range(n):
-                    eng.submit(i, refs[i], diss[i])
-                return eng.collect(0, n)
-        finally:
-            if old is None:
-                os.environ.pop("PQA_FUSE_MOTION", None)
-            else:
-                os.environ["PQA_FUSE_MOTION"] = old
-
-    plain, fused = run("0"), run("1")
-    assert np.array_equal(plain[:, :16].view(np.uint64), fused[:, :16].view(np.uint64))
-    assert fused[0, 16] == 0.0 and np.all(fused[1:, 16] > 0)
-    assert not np.array_equal(plain[:, 16], fused[:, 16]), "the switch did not change the path"
-    np.testing.assert_allclose(fused[:, 16], plain[:, 16], rtol=1e-6, atol=0)
-    exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc, vif_border101=bool(border))
-    assert np.abs(fused[:, 16] - exp[:, 16]).max() < 2e-5 + 5e-6 * exp[:, 16].max()
+        assert np.array_equal(odd.view(np.uint64), (mfma if bpc == 8 else valu).view(np.uint64))
 
 
 def test_worst_known_hd_flip_case_stays_bounded():
