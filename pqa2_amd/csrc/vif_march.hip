@@ -45,6 +45,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -68,7 +69,9 @@ enum : int {
   F_DD = 9,    // 9..11  the same for DIS in N slots 8..15
   F_V = 12,    // 12,13  pass 2, c * 2^8 in two pieces, K order {previous block rows, current block rows}
   F_VD = 14,   // 14,15  pass 2 of the next scale's input, c' * 2^8, even output rows in N slots 0..7
-  kMarchFrags = 16
+  F_W = 16,    // 16,17  as F_V with K order {current block rows, previous block rows}
+  F_WD = 18,   // 18,19  as F_VD in that order
+  kMarchFrags = 20
 };
 
 struct MarchArgs {
@@ -86,6 +89,7 @@ struct MarchArgs {
   unsigned dst_pitch_r, dst_pitch_d;       // floats
   int64_t dst_frame_pitch_r, dst_frame_pitch_d;
   int n_cb, n_cbg, seg_blocks, n_seg, row_blocks;
+  float mean_off, dec_off;                 // -128 * sum(17 taps) / 16 and -128 * sum(9 taps): the mid-grey term of the planes filtered as samples
   const uint4* tab;
 };
 
@@ -99,23 +103,40 @@ __device__ __forceinline__ unsigned tiny_minus(unsigned x, unsigned short off_bi
 }
 __device__ __forceinline__ f4 mma(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// Four f32 values (scaled by `s`, an exact power of two) -> two f16 pieces each: hi = rne(v), lo = rne(v - hi).
-// hi / lo: {piece(v0), piece(v1)}, {piece(v2), piece(v3)} -- the element order of an MFMA operand.
-__device__ __forceinline__ void split4(const f4 v, const float s, unsigned (&hi)[2], unsigned (&lo)[2]) {
-  const f2 a = f2{v[0], v[1]} * f2{s, s}, b = f2{v[2], v[3]} * f2{s, s};
-  const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
-  // v - hi is exact in f32 (hi shares v's leading bits); written as fma so that the f16 operand feeds v_fma_mix_f32
-  const f2 ra = f2{__builtin_fmaf((float)ha[0], -1.0f, a[0]), __builtin_fmaf((float)ha[1], -1.0f, a[1])};
-  const f2 rb = f2{__builtin_fmaf((float)hb[0], -1.0f, b[0]), __builtin_fmaf((float)hb[1], -1.0f, b[1])};
-  hi[0] = __builtin_bit_cast(unsigned, ha);
-  hi[1] = __builtin_bit_cast(unsigned, hb);
-  lo[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, h2));
-  lo[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(rb, h2));
+// v - hi for a value v and its f16 rounding hi (one half of a packed pair): exact in f32 (hi shares v's leading bits).
+// v_fma_mix_f32 reads the f16 half in place -- no conversion instruction, one VALU op per value.
+template <int HALF>
+__device__ __forceinline__ float residual(const unsigned hi_pair, const float v) {
+  float r;
+  if (HALF == 0)
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pair), "s"(-1.0f), "v"(v));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pair), "s"(-1.0f), "v"(v));
+  return r;
 }
 
-struct Pieces {          // one 16-row block after pass 1: rows 4 (lane >> 4) + i of column (lane & 15)
-  unsigned hi[5][2], lo[5][2];
-  unsigned dhi[2], dlo[2];   // next scale's input: N slot (lane & 15) = even column of ref (0..7) / dis (8..15)
+// Four f32 values v * s + b (s an exact power of two; b removes the mid-grey term of the mean planes, see pass1) -> two
+// f16 pieces each: hi = rne(x), lo = rne(x - hi).
+// hi / lo: {piece(x0), piece(x1)}, {piece(x2), piece(x3)} -- the element order of an MFMA operand.
+template <int HALF>   // which half of the operand vectors (0: dwords 0, 1; 1: dwords 2, 3) receives the pieces
+__device__ __forceinline__ void split4(const f4 v, const float s, const float b, u4v& hi, u4v& lo) {
+  const f2 xa = __builtin_elementwise_fma(f2{v[0], v[1]}, f2{s, s}, f2{b, b});
+  const f2 xb = __builtin_elementwise_fma(f2{v[2], v[3]}, f2{s, s}, f2{b, b});
+  const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(xa, h2));
+  const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(xb, h2));
+  const f2 ra = f2{residual<0>(h0, xa[0]), residual<1>(h0, xa[1])};
+  const f2 rb = f2{residual<0>(h1, xb[0]), residual<1>(h1, xb[1])};
+  hi[2 * HALF] = h0;
+  hi[2 * HALF + 1] = h1;
+  lo[2 * HALF] = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, h2));
+  lo[2 * HALF + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(rb, h2));
+}
+
+// The pieces of TWO consecutive 16-row blocks after pass 1 (rows 4 (lane >> 4) + i of column (lane & 15)), laid out as the
+// pass-2 operands themselves: dwords {0, 1} of each vector belong to the even block, {2, 3} to the odd one.  Plane 5 is
+// the next scale's input (N slot (lane & 15) = even column of ref (0..7) / dis (8..15)).
+struct Pieces {
+  u4v hi[6], lo[6];
 };
 
 // vif_statistic_s on two horizontally adjacent pixels, in units U = 16 (see the file comment): accumulates the low-branch
@@ -152,8 +173,27 @@ __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2
   s.den2 += wl;
 }
 
-__global__ __launch_bounds__(kBlock, 2) void vif_s0_march_kernel(const MarchArgs a) {
+// PQA_MARCH_LDS_TABLES: the tap fragments of the next scale's input (used once per block each) stay in LDS and are read
+// where they are used instead of occupying 40 VGPRs for the whole march; with them out of the way the kernel fits three
+// waves per SIMD (PQA_MARCH_OCC).
+#ifndef PQA_MARCH_LDS_TABLES
+#define PQA_MARCH_LDS_TABLES 1
+#endif
+#ifndef PQA_MARCH_OCC
+#define PQA_MARCH_OCC (PQA_MARCH_LDS_TABLES ? 3 : 2)
+#endif
+__global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(const MarchArgs a) {
   const int tid = threadIdx.x;
+#if PQA_MARCH_LDS_TABLES
+  // fragments F_DR .. F_DD + 2 (6), F_VD, F_VD + 1, F_WD, F_WD + 1 -> LDS slots 0..9
+  __shared__ uint4 stab[10 * 64];
+  for (int i = tid; i < 10 * 64; i += kBlock) {
+    const int f = i >> 6;
+    const int src = f < 6 ? F_DR + f : f < 8 ? F_VD + (f - 6) : F_WD + (f - 8);
+    stab[i] = a.tab[src * 64 + (i & 63)];
+  }
+  __syncthreads();
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int id = xcd_remap(blockIdx.x, a.n_cbg * a.n_seg);
   const int cbg = id % a.n_cbg, seg = id / a.n_cbg;
@@ -181,12 +221,38 @@ __global__ __launch_bounds__(kBlock, 2) void vif_s0_march_kernel(const MarchArgs
   // tap-matrix fragments of this lane
   h8 T[kMarchFrags];
 #pragma unroll
-  for (int f = 0; f < kMarchFrags; ++f) T[f] = __builtin_bit_cast(h8, a.tab[f * 64 + lane]);
+  for (int f = 0; f < kMarchFrags; ++f) {
+    const bool in_lds = PQA_MARCH_LDS_TABLES && ((f >= F_DR && f < F_DR + 6) || (f >= F_VD && f < F_VD + 2) || f >= F_WD);
+    if (!in_lds) T[f] = __builtin_bit_cast(h8, a.tab[f * 64 + lane]);
+  }
+#if PQA_MARCH_LDS_TABLES
+  // a fragment kept in LDS, read where it is used.  The lane's byte offset goes through an empty asm once per pass (tab_off,
+  // refreshed by TD_REFRESH): the reads of a pass can then be scheduled together and early, but not hoisted out of the
+  // march (which would put every fragment back into 4 VGPRs for the whole loop)
+  int tab_off = lane * 16;
+  const auto lds_frag = [&](const int slot) {
+    return __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(stab) + tab_off + slot * 1024));
+  };
+#define TD_REFRESH() asm volatile("" : "+v"(tab_off))
+#define TD(f) lds_frag((f) < F_VD ? (f) - F_DR : (f) < F_W ? 6 + (f) - F_VD : 8 + (f) - F_WD)
+#else
+#define TD_REFRESH()
+#define TD(f) T[f]
+#endif
 
   // ---- loads: 8 consecutive samples of row (block row m) per image ----------------------------------------------
+  // A block whose 16 rows lie inside the image needs no per-lane row arithmetic at all: the lane part of the address
+  // (m * pitch + first column) is fixed for the whole march and the block's first row goes into the load's SCALAR offset.
+  const unsigned lane_off_r = (unsigned)m * a.pitch_r + (unsigned)xin, lane_off_d = (unsigned)m * a.pitch_d + (unsigned)xin;
   const auto load_block = [&](int rb, u2v& R, u2v& D) {
-    const int yin = ys - 8 + 16 * rb + m;
-    const unsigned my = (unsigned)mirror_fold(yin, a.h, a.fold_h);
+    const int y_first = ys - 8 + 16 * rb;                                 // wave-uniform
+    const bool rows_in = y_first >= 0 && y_first + 16 <= a.h;
+    if (colfast && rows_in) {
+      R = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, lane_off_r, (unsigned)y_first * a.pitch_r, 0));
+      D = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, lane_off_d, (unsigned)y_first * a.pitch_d, 0));
+      return;
+    }
+    const unsigned my = (unsigned)mirror_fold(y_first + m, a.h, a.fold_h);
     if (colfast) {
       R = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, my * a.pitch_r + (unsigned)xin, 0, 0));
       D = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, my * a.pitch_d + (unsigned)xin, 0, 0));
@@ -204,7 +270,9 @@ __global__ __launch_bounds__(kBlock, 2) void vif_s0_march_kernel(const MarchArgs
   };
 
   // ---- pass 1 + split: one 16 x 32 input block -> this lane's pieces -----------------------------------------------
-  const auto pass1 = [&](const u2v R, const u2v D, Pieces& P) {
+  const auto pass1 = [&](const u2v R, const u2v D, Pieces& P, auto half) {
+    constexpr int H = decltype(half)::value;
+    TD_REFRESH();
     const f4 z = f4{0.0f, 0.0f, 0.0f, 0.0f};
     // 16-bit lanes {col 2v, col 2v+1} of this lane's 8 columns: byte -> zero-extended half (one v_perm_b32 each)
     unsigned ru[4], du[4], r16[4], d16[4], t[4];
@@ -217,21 +285,18 @@ __global__ __launch_bounds__(kBlock, 2) void vif_s0_march_kernel(const MarchArgs
       d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{128, 128});
     }
     f4 Dh[5], Dd;
-    {  // means r' and d' = (sample - 128) * 2^-24, and the next scale's input from the same operands
-#pragma unroll
-      for (int v = 0; v < 4; ++v) t[v] = tiny_minus(ru[v], 0x8080);
-      const h8 A = frag4(t[0], t[1], t[2], t[3]);
-      Dh[0] = mma(A, T[F_LO], z); Dd = mma(A, T[F_DR], z);
-      Dh[0] = mma(A, T[F_LO + 1], Dh[0]); Dd = mma(A, T[F_DR + 1], Dd);
-      Dh[0] = mma(A, T[F_LO + 2], Dh[0]); Dd = mma(A, T[F_DR + 2], Dd);
+    {  // means and the next scale's input: the SAMPLES themselves (k * 2^-24); the mid-grey term 128 * sum(taps) is a constant
+       // of the filter (mirrored borders keep all 17 / 9 taps inside the window) and comes off in the split's fma
+      const h8 A = frag4(ru[0], ru[1], ru[2], ru[3]);
+      Dh[0] = mma(A, T[F_LO], z); Dd = mma(A, TD(F_DR), z);
+      Dh[0] = mma(A, T[F_LO + 1], Dh[0]); Dd = mma(A, TD(F_DR + 1), Dd);
+      Dh[0] = mma(A, T[F_LO + 2], Dh[0]); Dd = mma(A, TD(F_DR + 2), Dd);
     }
     {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) t[v] = tiny_minus(du[v], 0x8080);
-      const h8 A = frag4(t[0], t[1], t[2], t[3]);
-      Dh[1] = mma(A, T[F_LO], z); Dd = mma(A, T[F_DD], Dd);
-      Dh[1] = mma(A, T[F_LO + 1], Dh[1]); Dd = mma(A, T[F_DD + 1], Dd);
-      Dh[1] = mma(A, T[F_LO + 2], Dh[1]); Dd = mma(A, T[F_DD + 2], Dd);
+      const h8 A = frag4(du[0], du[1], du[2], du[3]);
+      Dh[1] = mma(A, T[F_LO], z); Dd = mma(A, TD(F_DD), Dd);
+      Dh[1] = mma(A, T[F_LO + 1], Dh[1]); Dd = mma(A, TD(F_DD + 1), Dd);
+      Dh[1] = mma(A, T[F_LO + 2], Dh[1]); Dd = mma(A, TD(F_DD + 2), Dd);
     }
 #pragma unroll
     for (int s = 2; s < 5; ++s) {   // r'^2, d'^2, r'd': exact 16-bit integer products, digits base 256
@@ -265,12 +330,13 @@ __global__ __launch_bounds__(kBlock, 2) void vif_s0_march_kernel(const MarchArgs
     // pass 1 leaves every signal times 2^-13 and the next scale's input times 2^-6 (operands k * 2^-24, pieces of
     // c * 2^11, c * 2^19 on the digits that weigh 2^8, c' * 2^18).  Into pass 2: means as natural / 16, squares as natural,
     // the next scale's input as natural.
-    split4(Dh[0], 512.0f, P.hi[0], P.lo[0]);
-    split4(Dh[1], 512.0f, P.hi[1], P.lo[1]);
-    split4(Dh[2], 8192.0f, P.hi[2], P.lo[2]);
-    split4(Dh[3], 8192.0f, P.hi[3], P.lo[3]);
-    split4(Dh[4], 8192.0f, P.hi[4], P.lo[4]);
-    split4(Dd, 64.0f, P.dhi, P.dlo);
+    // The means were filtered as samples: sum c (x - 128) = sum c x - 128 sum c, with sum c the exact sum of the f32 taps.
+    split4<H>(Dh[0], 512.0f, a.mean_off, P.hi[0], P.lo[0]);
+    split4<H>(Dh[1], 512.0f, a.mean_off, P.hi[1], P.lo[1]);
+    split4<H>(Dh[2], 8192.0f, 0.0f, P.hi[2], P.lo[2]);
+    split4<H>(Dh[3], 8192.0f, 0.0f, P.hi[3], P.lo[3]);
+    split4<H>(Dh[4], 8192.0f, 0.0f, P.hi[4], P.lo[4]);
+    split4<H>(Dd, 64.0f, a.dec_off, P.hi[5], P.lo[5]);
   };
 
   double dnum = 0.0, dden = 0.0;
@@ -280,63 +346,85 @@ __global__ __launch_bounds__(kBlock, 2) void vif_s0_march_kernel(const MarchArgs
   for (int i = 0; i < 4; ++i) vcol[i] = x0 + 4 * kq + i < a.w;
   const int ow = a.w >> 1, oh = a.h >> 1;
 
-  Pieces prev, cur;
-  u2v Rn, Dn;
-  load_block(0, Rn, Dn);
-  for (int rb = 0; rb <= n_out; ++rb) {
-    const u2v Rc = Rn, Dc = Dn;
-    if (rb < n_out) load_block(rb + 1, Rn, Dn);   // in flight while this block is computed
-    pass1(Rc, Dc, cur);
-    if (rb > 0) {
-      // ---- pass 2: window = (previous block, current block); out rows yo .. yo + 15, this lane: row yo + m, cols 4 kq + i
-      const int yo = ys + 16 * (rb - 1);
-      const f4 z = f4{0.0f, 0.0f, 0.0f, 0.0f};
-      f4 V[5];
+  // ---- pass 2 + next-scale store + statistic for output rows yo .. yo + 15: the window is the pair of blocks in P;
+  // FV / FVD = the tap fragments whose K order matches which half holds the OLDER block
+  const auto pass2 = [&](const Pieces& P, const int FV, const int FVD, const int yo) {
+    TD_REFRESH();
+    const f4 z = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    f4 V[5];
 #pragma unroll
-      for (int s = 0; s < 5; ++s) {
-        const h8 Ah = frag4(prev.hi[s][0], prev.hi[s][1], cur.hi[s][0], cur.hi[s][1]);
-        const h8 Al = frag4(prev.lo[s][0], prev.lo[s][1], cur.lo[s][0], cur.lo[s][1]);
-        V[s] = mma(Ah, T[F_V], z);
-        V[s] = mma(Ah, T[F_V + 1], V[s]);
-        V[s] = mma(Al, T[F_V], V[s]);
-      }
-      f4 Vd;
-      {
-        const h8 Ah = frag4(prev.dhi[0], prev.dhi[1], cur.dhi[0], cur.dhi[1]);
-        const h8 Al = frag4(prev.dlo[0], prev.dlo[1], cur.dlo[0], cur.dlo[1]);
-        Vd = mma(Ah, T[F_VD], z);
-        Vd = mma(Ah, T[F_VD + 1], Vd);
-        Vd = mma(Al, T[F_VD], Vd);
-      }
-      // ---- next scale's input: lanes m < 8 hold 4 consecutive samples of half-resolution row yo / 2 + m --------------
-      if (m < 8) {
-        const int orow = (yo >> 1) + m, oc = (x0 >> 1) + 4 * (kq & 1);
-        if (orow < oh && oc < ow) {
-          float* __restrict__ dst = kq < 2 ? a.dst_ref + (int64_t)fr * a.dst_frame_pitch_r + (int64_t)orow * a.dst_pitch_r + oc
-                                           : a.dst_dis + (int64_t)fr * a.dst_frame_pitch_d + (int64_t)orow * a.dst_pitch_d + oc;
-          const f4 o = Vd * f4{1.0f / 256.0f, 1.0f / 256.0f, 1.0f / 256.0f, 1.0f / 256.0f};
-          if (oc + 4 <= ow) {
-            *reinterpret_cast<f4*>(dst) = o;
-          } else {
+    for (int s = 0; s < 5; ++s) {
+      const h8 Ah = __builtin_bit_cast(h8, P.hi[s]), Al = __builtin_bit_cast(h8, P.lo[s]);
+      V[s] = mma(Ah, T[FV], z);
+      V[s] = mma(Ah, T[FV + 1], V[s]);
+      V[s] = mma(Al, T[FV], V[s]);
+    }
+    f4 Vd;
+    {
+      const h8 Ah = __builtin_bit_cast(h8, P.hi[5]), Al = __builtin_bit_cast(h8, P.lo[5]);
+      const h8 t0 = TD(FVD), t1 = TD(FVD + 1);
+      Vd = mma(Ah, t0, z);
+      Vd = mma(Ah, t1, Vd);
+      Vd = mma(Al, t0, Vd);
+    }
+    // next scale's input: lanes m < 8 hold 4 consecutive samples of half-resolution row yo / 2 + m
+    if (m < 8) {
+      const int orow = (yo >> 1) + m, oc = (x0 >> 1) + 4 * (kq & 1);
+      if (orow < oh && oc < ow) {
+        float* __restrict__ dst = kq < 2 ? a.dst_ref + (int64_t)fr * a.dst_frame_pitch_r + (int64_t)orow * a.dst_pitch_r + oc
+                                         : a.dst_dis + (int64_t)fr * a.dst_frame_pitch_d + (int64_t)orow * a.dst_pitch_d + oc;
+        const f4 o = Vd * f4{1.0f / 256.0f, 1.0f / 256.0f, 1.0f / 256.0f, 1.0f / 256.0f};
+        if (oc + 4 <= ow) {
+          *reinterpret_cast<f4*>(dst) = o;
+        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (oc + i < ow) dst[i] = o[i];
-          }
+          for (int i = 0; i < 4; ++i)
+            if (oc + i < ow) dst[i] = o[i];
         }
       }
-      // ---- statistic on this lane's 4 pixels --------------------------------------------------------------------------
-      const bool vrow = yo + m < a.h;
-      StatAcc st{f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}};
-      stat_pair(st, f2{V[0][0], V[0][1]}, f2{V[1][0], V[1][1]}, f2{V[2][0], V[2][1]}, f2{V[3][0], V[3][1]},
-                f2{V[4][0], V[4][1]}, vrow && vcol[0], vrow && vcol[1], a.gain_limit);
-      stat_pair(st, f2{V[0][2], V[0][3]}, f2{V[1][2], V[1][3]}, f2{V[2][2], V[2][3]}, f2{V[3][2], V[3][3]},
-                f2{V[4][2], V[4][3]}, vrow && vcol[2], vrow && vcol[3], a.gain_limit);
-      const float num = (st.num2.x + st.num2.y) + ((fast_log2(st.pn.x) - fast_log2(st.qn.x)) + (fast_log2(st.pn.y) - fast_log2(st.qn.y)));
-      const float den = (st.den2.x + st.den2.y) + (fast_log2(st.pd.x) + fast_log2(st.pd.y));
-      dnum += (double)num;
-      dden += (double)den;
     }
-    prev = cur;
+    // statistic on this lane's 4 pixels (row yo + m, columns x0 + 4 kq + i)
+    const bool vrow = yo + m < a.h;
+    StatAcc st{f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}};
+    stat_pair(st, f2{V[0][0], V[0][1]}, f2{V[1][0], V[1][1]}, f2{V[2][0], V[2][1]}, f2{V[3][0], V[3][1]},
+              f2{V[4][0], V[4][1]}, vrow && vcol[0], vrow && vcol[1], a.gain_limit);
+    stat_pair(st, f2{V[0][2], V[0][3]}, f2{V[1][2], V[1][3]}, f2{V[2][2], V[2][3]}, f2{V[3][2], V[3][3]},
+              f2{V[4][2], V[4][3]}, vrow && vcol[2], vrow && vcol[3], a.gain_limit);
+    const float num = (st.num2.x + st.num2.y) + ((fast_log2(st.pn.x) - fast_log2(st.qn.x)) + (fast_log2(st.pn.y) - fast_log2(st.qn.y)));
+    const float den = (st.den2.x + st.den2.y) + (fast_log2(st.pd.x) + fast_log2(st.pd.y));
+    dnum += (double)num;
+    dden += (double)den;
+  };
+
+  // Blocks alternate between the two halves of the operand vectors: the even blocks live in dwords {0, 1}, the odd ones in
+  // {2, 3}, so the pass-2 operand is always the vector as it stands -- four consecutive registers per plane that are never
+  // copied.  Which half is the older block flips every step, so the tap fragments exist in both K orders (F_V / F_VD:
+  // {older, newer}; F_W / F_WD: {newer, older}).
+  Pieces P;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { P.hi[i] = u4v{0u, 0u, 0u, 0u}; P.lo[i] = u4v{0u, 0u, 0u, 0u}; }
+  const std::integral_constant<int, 0> even{};
+  const std::integral_constant<int, 1> odd{};
+  u2v Rn, Dn;
+  load_block(0, Rn, Dn);
+  {
+    const u2v Rc = Rn, Dc = Dn;
+    load_block(1, Rn, Dn);   // n_out >= 1: block 1 always exists
+    pass1(Rc, Dc, P, even);
+  }
+  for (int rb = 1; rb <= n_out; rb += 2) {
+    {   // odd block -> upper half; window (lower half older, upper half newer)
+      const u2v Rc = Rn, Dc = Dn;
+      if (rb < n_out) load_block(rb + 1, Rn, Dn);   // in flight while this block is computed
+      pass1(Rc, Dc, P, odd);
+      pass2(P, F_V, F_VD, ys + 16 * (rb - 1));
+    }
+    if (rb + 1 <= n_out) {   // even block -> lower half; window (lower half newer, upper half older)
+      const u2v Rc = Rn, Dc = Dn;
+      if (rb + 1 < n_out) load_block(rb + 2, Rn, Dn);
+      pass1(Rc, Dc, P, even);
+      pass2(P, F_W, F_WD, ys + 16 * rb);
+    }
   }
   dnum = wave_sum(dnum);
   dden = wave_sum(dden);
@@ -396,6 +484,11 @@ bool build_table(uint16_t* out /* [kMarchFrags][64][8] */) {
       pieces((tv >= 0 && tv <= 16) ? (double)c17[tv] * 256.0 : 0.0, 2, o + F_V * stride, stride);
       const int tv9 = wr - (2 * n + 4);   // N slot n < 8 = even output row 2 n
       pieces((n < 8 && tv9 >= 0 && tv9 <= 8) ? (double)c9[tv9] * 256.0 : 0.0, 2, o + F_VD * stride, stride);
+      // the same with the register halves swapped: K element j < 4 = current block, j >= 4 = previous block
+      const int ws = j < 4 ? 16 + 4 * kb + j : 4 * kb + (j - 4);
+      const int tw = ws - n, tw9 = ws - (2 * n + 4);
+      pieces((tw >= 0 && tw <= 16) ? (double)c17[tw] * 256.0 : 0.0, 2, o + F_W * stride, stride);
+      pieces((n < 8 && tw9 >= 0 && tw9 <= 8) ? (double)c9[tw9] * 256.0 : 0.0, 2, o + F_WD * stride, stride);
     }
   }
   return exact;
@@ -435,7 +528,7 @@ hipError_t vif_march_prepare() {
     (void)hipFree(d);
     return e;
   }
-  g_tab[dev] = (const uint4*)d;   // lives as long as the process (16 KB per device)
+  g_tab[dev] = (const uint4*)d;   // lives as long as the process (20 KB per device)
   return hipSuccess;
 }
 
@@ -462,13 +555,26 @@ bool launch_vif_s0_march(hipStream_t stream, PlaneRun ref, PlaneRun dis, int n_f
   if (((uintptr_t)a.dst_ref | (uintptr_t)a.dst_dis) & 15 || (a.dst_pitch_r | a.dst_pitch_d) & 3 ||
       (a.dst_frame_pitch_r | a.dst_frame_pitch_d) & 3)
     return false;
+  {
+    float c17[17], c9[9];
+    gaussian(17, c17);
+    gaussian(9, c9);
+    double s17 = 0.0, s9 = 0.0;
+    for (int k = 0; k < 17; ++k) s17 += (double)c17[k];
+    for (int k = 0; k < 9; ++k) s9 += (double)c9[k];
+    a.mean_off = (float)(-128.0 * s17 / 16.0);
+    a.dec_off = (float)(-128.0 * s9);
+  }
   a.n_cb = (w + 15) / 16;
   a.n_cbg = (a.n_cb + 3) / 4;
   a.row_blocks = (h + 15) / 16;
   // segment length: long enough that the repeated first block is cheap, short enough that a launch has several waves
   // per SIMD slot to balance (2 048 wave slots at two waves per SIMD)
   int seg = a.row_blocks;
-  const long long want_waves = 6 * 2048;
+#ifndef PQA_MARCH_WANT_WAVES
+#define PQA_MARCH_WANT_WAVES (16 * 3072)   /* swept 6 144 / 12 288 / 49 152 / 98 304 on the box: 49 152 best by 1 % */
+#endif
+  const long long want_waves = PQA_MARCH_WANT_WAVES;
   while (seg > kMinSegBlocks && (long long)a.n_cbg * 4 * ((a.row_blocks + seg - 1) / seg) * n_frames < want_waves) seg = (seg + 1) / 2;
   if (seg < kMinSegBlocks) seg = a.row_blocks < kMinSegBlocks ? a.row_blocks : kMinSegBlocks;
   a.seg_blocks = seg;
