@@ -231,12 +231,16 @@ def main():
             traffic = int(per_frame * frames_per_launch) if per_frame else None
             if args.fixed_point & 1:
                 kname = f"vif_fixed_kernel<{'u8' if bpc == 8 else 'u16'},17,240,9>"
-            elif bpc <= 10:   # the matrix-core kernel, interior launch + edge launch, timed together
-                kname = (f"vif_s0_mfma_kernel<{'u8' if bpc == 8 else 'u16'},false> + <..,true> (interior + edge tile pairs; "
-                         f"17-tap vertical pass on f16 MFMA)")
+            elif bpc == 8:    # the march kernel: both filter passes on the f16 matrix cores (csrc/vif_march.hip)
+                kname = "vif_s0_march_kernel (17-tap horizontal pass exact on f16 MFMA, vertical pass on two-piece f16 splits)"
+            elif bpc <= 10:   # the round-2 kernel, interior launch + edge launch, timed together
+                kname = ("vif_s0_mfma_kernel<u16,false> + <..,true> (interior + edge tile pairs; 17-tap vertical pass on f16 MFMA)")
             else:
                 kname = "vif_stat_kernel<u16,17,240,9>"
-            out["roofline"] = {"bound": "hbm", "kernel": kname + " (VIF scale 0 + fused decimation to scale 1)",
+            out["roofline"] = {"bound": "hbm", "bound_is_measured_limiter": False,
+                               "bound_note": "north_star names the HBM roofline, so `frac` is priced against it; the kernel's measured "
+                                             "limiter is vector + matrix instruction issue (`measured_limiter`, `valu`, `mfma`)",
+                               "kernel": kname + " (VIF scale 0 + fused decimation to scale 1)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5),
                                "traffic": traffic,
@@ -246,7 +250,8 @@ def main():
                                # SURVEY 8(d)'s primary formula for the WHOLE path: frames/s x B_alg / HBM peak
                                "pipeline_frac": round(fps / world * b_alg / (HBM_PEAK_GBS * 1e9), 5),
                                # what actually limits the kernel: FP32 issue, not bytes
-                               "measured_limiter": "VALU issue cycles (FP32 FMA rate + 4-clock non-FMA instructions) and the matrix pipe they share, not HBM: see `valu`, `mfma`"}
+                               "measured_limiter": "instruction issue: VALU (4 clk per wave64 instruction) + MFMA (8 issue clk of 16 each) on "
+                                                   "one port per SIMD, 80 % busy at 3 waves per SIMD (profiles/*_sq_counters.txt); not HBM: see `valu`, `mfma`"}
             if cnt.get("valu_insts_per_wave"):
                 # issue floor = VALU instructions per wave x waves / (1024 SIMDs x one wave64 instruction per 4 clocks)
                 clk = cnt.get("shader_clock_ghz", 2.0)
@@ -258,21 +263,34 @@ def main():
                     "valu_wave_insts_per_frame": int(wave_insts),
                     "shader_clock_ghz": clk, "issue_floor_us_per_frame": round(floor_us, 2),
                     "measured_us_per_frame": round(meas_us, 2), "frac": round(floor_us / meas_us, 4),
-                    "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk: what v_pk_fma_f32 (2 FMA per lane: 157 TFLOP/s) AND "
-                                 "every non-FMA instruction (convert, select, permute, copy) cost; plain v_fma_f32 takes about 2 clk; "
-                                 "SQ_INSTS_VALU counts the 108 MFMAs per wave too, which hold the pipe 16 clk each with about half "
-                                 "of that hidden under non-FMA VALU work (profiles/r02a_ubench_*.txt, r02j_ubench_mfma_plain_coissue.txt): "
-                                 "a count-based floor, not a cycle model",
+                    "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk: what every non-FMA instruction (convert, select, "
+                                 "permute) and v_pk_fma_f32 cost; SQ_INSTS_VALU counts the MFMAs too (45 per 16 x 16 block), which "
+                                 "hold the issue port 8 clk of their 16 (MI355X_MICROARCH.md cycle constants): a count-based floor, "
+                                 "not a cycle model",
                     "source": cnt.get("valu_source")}
             if bpc <= 10 and not args.fixed_point:
-                # matrix-core share of the same launches: 108 v_mfma_f32_16x16x32_f16 (16384 FLOP each) per wave and
-                # 16-row tile pair, 4 waves per pair (csrc/vif.hip); dense f16 peak 2.5 PFLOP/s (MI355X_MICROARCH.md)
-                pairs = ((w + 239) // 240) * (((h + 7) // 8) // 2)
-                mf = pairs * 4 * 108 * 16384.0
+                # matrix-core share of the same launches (v_mfma_f32_16x16x32_f16 = 16384 FLOP each; dense f16 peak
+                # 2.5 PFLOP/s, MI355X_MICROARCH.md)
+                if bpc == 8:
+                    # march kernel: per 16 x 16 block 27 MFMAs in pass 1 (repeated once per segment) + 18 in pass 2
+                    n_cb, rbk = (w + 15) // 16, (h + 15) // 16
+                    n_cbg = (n_cb + 3) // 4
+                    seg = rbk
+                    while seg > 8 and n_cbg * 4 * ((rbk + seg - 1) // seg) * args.batch < 16 * 3072:
+                        seg = (seg + 1) // 2
+                    seg = max(seg, min(rbk, 8))
+                    n_seg = (rbk + seg - 1) // seg
+                    mf = n_cb * (27 * (rbk + n_seg) + 18 * rbk) * 16384.0
+                    note = ("45 MFMAs per 16 x 16 output block (27 exact first-pass + 18 second-pass); a Toeplitz band uses 17 of "
+                            "the 32 K slots, so the USEFUL share of these FLOP is about half")
+                else:
+                    pairs = ((w + 239) // 240) * (((h + 7) // 8) // 2)
+                    mf = pairs * 4 * 108 * 16384.0
+                    note = "108 MFMAs per wave and 16-row tile pair, 4 waves per pair (csrc/vif.hip)"
                 out["roofline"]["mfma"] = {"flop_per_frame": mf, "achieved_tflops": round(mf * frames_per_launch / (avg_ms * 1e-3) / 1e12, 1),
                                            "peak_tflops": 2500.0, "frac": round(mf * frames_per_launch / (avg_ms * 1e-3) / 2.5e15, 4),
-                                           "note": "the matrix pipe is shared with packed FP32 (tools/ubench/mfma_coissue.hip): the "
-                                                   "kernel's limiter is FP32 issue + this, not either alone"}
+                                           "note": note + "; the matrix pipe shares its issue port with the VALU: neither fraction can "
+                                                          "approach 1 alone"}
             out["kernel_ms_per_frame"] = {name: round(v["ms"] / max(1, v["frames"]), 5)
                                           for name, v in breakdown.items() if v["launches"]}
             out["kernel_ms_note"] = "from one extra untimed pass with every kernel event-timed (ms per frame)"
@@ -287,7 +305,17 @@ def main():
         if world == 1 and args.workload == "2160p" and not args.fixed_point and not args.no_e2e:
             out["e2e"] = _e2e_leg()
             out["bookend"] = _bookend_leg()
-        out["libvmaf_side_by_side"] = "not available: no ffmpeg / libvmaf on this box (cpu_baseline.kind = port)"
+        probe = probe_libvmaf()
+        if probe["ffmpeg_has_libvmaf"] and world == 1 and not args.no_cpu_baseline:
+            n_lv = min(F, 60 if w * h > 1920 * 1080 else 150)
+            out["libvmaf_side_by_side"] = {"probe": probe, **_libvmaf_leg(probe, ref_t, dis_t, halo, bpc, w, h, model_name,
+                                                                           result["vmaf"], n_lv)}
+        else:
+            out["libvmaf_side_by_side"] = {"probe": probe,
+                                           "result": "not run: no ffmpeg with the libvmaf filter on this box (probed PATH and "
+                                                     "`ffmpeg -filters`; a `vmaf` CLI alone is reported but not driven); "
+                                                     "cpu_baseline.kind = port, parity against libvmaf stays unpinned"
+                                                     if not probe["ffmpeg_has_libvmaf"] else "not run (N > 1 or --no-cpu-baseline)"}
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
@@ -317,26 +345,95 @@ def _other_configs(args):
 def _e2e_leg():
     """SURVEY 8(d) end-to-end leg: two 4:2:0 Y4M files on disk -> VMAFAnalyzer.analyze_videos() (host planes -> pinned
     staging -> H2D overlapped with the kernels -> SVM -> libvmaf-format JSON + psnr/ssim stats files), wall clock, in a
-    child process per size (tools/e2e_file_bench.py).  PCIe- and memcpy-bound; never part of `value`."""
+    child process per size (tools/e2e_file_bench.py), 300 frames as BASELINE.json's configs.  Both analyses of the
+    process are reported -- the FIRST (context creation + pinning the staging buffers: what a one-shot caller gets) and the
+    second (staging parked in the library) -- next to the host-to-device copy ceiling measured in the same process.
+    PCIe- and memcpy-bound; never part of `value`."""
     import shutil
     import subprocess
     import tempfile
     out = {}
-    for size, frames in (("1920x1080", 150), ("3840x2160", 48)):
+    for size, frames in (("1920x1080", 300), ("3840x2160", 300)):
         d = tempfile.mkdtemp(prefix="pqa_e2e_")
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_file_bench.py"), "--size", size,
-                                "--frames", str(frames), "--dir", d], capture_output=True, text=True, timeout=300)
+                                "--frames", str(frames), "--dir", d], capture_output=True, text=True, timeout=600)
             lines = [json.loads(x) for x in r.stdout.strip().splitlines() if x.startswith("{")]
-            best = max(lines, key=lambda x: x["fps_end_to_end"])
-            out[size] = {"fps_end_to_end": best["fps_end_to_end"], "frames": frames, "seconds": best["seconds"],
-                         "what": "2 Y4M files (page cache) -> analyze_videos -> JSON + psnr.txt + ssim.txt, all planes, "
-                                 "vmaf_v0.6.1; context creation and file writing included; the better of two passes in one "
-                                 "process (the second finds the pinned staging buffers of the first parked in the library)"}
+            passes = {x["pass"]: x for x in lines if "pass" in x}
+            link = next((x for x in lines if "h2d_GBps" in x), {})
+            out[size] = {"frames": frames,
+                         "first_analysis_fps": passes[0]["fps_end_to_end"], "first_analysis_seconds": passes[0]["seconds"],
+                         "second_analysis_fps": passes[1]["fps_end_to_end"], "second_analysis_seconds": passes[1]["seconds"],
+                         "h2d_GBps": link.get("h2d_GBps"), "bytes_per_frame_pair": link.get("bytes_per_frame_pair"),
+                         "pcie_ceiling_fps": link.get("pcie_ceiling_fps"),
+                         "what": "2 Y4M files (written just before: page cache) -> analyze_videos -> JSON + psnr.txt + ssim.txt, "
+                                 "all planes, vmaf_v0.6.1; context creation and file writing included; first = cold pinned "
+                                 "staging, second = staging parked by the first; ceiling = bytes per frame pair / measured "
+                                 "pinned H2D rate"}
         except Exception as e:
             out[size] = {"error": (str(e) or "failed")[:200]}
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def probe_libvmaf():
+    """BASELINE.md section 3 step 1 / SURVEY 8(d): is there an ffmpeg with the libvmaf filter, or a `vmaf` CLI, on this
+    box?  No installation, no download: a lookup on PATH and `ffmpeg -hide_banner -filters`."""
+    import shutil
+    import subprocess
+    info = {"ffmpeg": shutil.which("ffmpeg"), "vmaf_cli": shutil.which("vmaf"), "ffmpeg_has_libvmaf": False,
+            "ffmpeg_version": None}
+    if info["ffmpeg"]:
+        try:
+            r = subprocess.run([info["ffmpeg"], "-hide_banner", "-filters"], capture_output=True, text=True, timeout=30)
+            info["ffmpeg_has_libvmaf"] = any(len(l.split()) > 1 and l.split()[1] == "libvmaf" for l in r.stdout.splitlines())
+            v = subprocess.run([info["ffmpeg"], "-version"], capture_output=True, text=True, timeout=30)
+            info["ffmpeg_version"] = (v.stdout.splitlines() or [None])[0]
+        except Exception as e:
+            info["probe_error"] = str(e)[:200]
+    return info
+
+
+def _libvmaf_leg(probe, ref_t, dis_t, halo, bpc, w, h, model_name, gpu_vmaf, n_frames):
+    """The reference's own command (app/vmaf_analyzer.py:411-419) on the first `n_frames` frames of the bench clip, with
+    n_threads = 4 (the reference's fixed default, :32) and = all usable cores: frames / wall clock, and the per-frame
+    `vmaf` of its JSON log against ours.  Only runs when probe_libvmaf() found the filter."""
+    import shutil
+    import subprocess
+    import tempfile
+    from pqa2_amd import synth, yuvio
+    d = tempfile.mkdtemp(prefix="pqa_libvmaf_")
+    out = {"frames": n_frames, "ffmpeg_version": probe.get("ffmpeg_version"), "host_cores": os.cpu_count()}
+    try:
+        info = synth.clip_info(w, h, bpc, chroma=False)
+        paths = {}
+        for side, t in (("ref", ref_t), ("dis", dis_t)):
+            paths[side] = os.path.join(d, f"{side}.y4m")
+            frames = ([t[0][halo + i].cpu().numpy().view(np.uint16 if bpc > 8 else np.uint8)] for i in range(n_frames))
+            yuvio.write_y4m(paths[side], frames, info)
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+        for threads in sorted({4, avail}):
+            log = os.path.join(d, f"vmaf_t{threads}.json")
+            opt = f"libvmaf=log_path={log}:log_fmt=json:model=version={model_name}:n_threads={threads}:n_subsample=1"
+            t0 = time.perf_counter()
+            r = subprocess.run([probe["ffmpeg"], "-hide_banner", "-loglevel", "info", "-i", paths["dis"], "-i", paths["ref"],
+                                "-lavfi", opt, "-f", "null", "-"], capture_output=True, text=True, timeout=1200)
+            dt = time.perf_counter() - t0
+            rec = {"fps": round(n_frames / dt, 3), "seconds": round(dt, 2), "returncode": r.returncode}
+            try:
+                with open(log) as f:
+                    lv = json.load(f)
+                theirs = np.array([fr["metrics"]["vmaf"] for fr in lv["frames"]][:n_frames])
+                rec["max_abs_vmaf_diff_per_frame"] = float(np.abs(theirs - gpu_vmaf[:len(theirs)]).max())
+                rec["pooled_abs_vmaf_diff"] = float(abs(theirs.mean() - gpu_vmaf[:len(theirs)].mean()))
+            except Exception as e:
+                rec["log_error"] = str(e)[:200]
+            out[f"n_threads_{threads}"] = rec
+    except Exception as e:
+        out["error"] = str(e)[:300]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     return out
 
 

@@ -698,8 +698,10 @@ int flush_pending(pqa_ctx* c) {
     r.frame_pitch[p] = d.frame_pitch[p] = (int64_t)c->slot_bytes;
   }
   const int n = c->pending;
+  int rc = check_slots_free(c, c->pending_first, n);
+  if (rc != PQA_OK) return rc;   // PQA_ESTATE: nothing launched, the packed frames stay pending (collect, then flush again)
   c->pending = 0;
-  int rc = process_batch(c, c->pending_first, n, &r, &d, nullptr, 0);
+  rc = process_batch(c, c->pending_first, n, &r, &d, nullptr, 0);
   if (rc != PQA_OK) return rc;
   HIPCHK(c, hipEventRecord(H.computed, c->stream));
   H.computed_pending = true;
@@ -985,6 +987,7 @@ int pqa_submit_device(pqa_ctx* c, int64_t first_index, int32_t n_frames, const p
   HIPCHK(c, hipSetDevice(c->device));
   int rc = flush_pending(c);
   if (rc != PQA_OK) return rc;
+  if ((rc = check_slots_free(c, first_index, n_frames)) != PQA_OK) return rc;   // the whole run, before any batch is launched
   for (int done = 0; done < n_frames;) {
     if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
     const int n = n_frames - done < c->B ? n_frames - done : c->B;
@@ -1103,16 +1106,19 @@ int pqa_submit(pqa_ctx* c, int64_t frame_index, const void* const ref_planes[3],
     return fail(c, PQA_EINVAL, "bad argument");
   if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = check_slots_free(c, frame_index, 1);  // before anything is packed: the caller can collect and retry
+  int rc = PQA_OK;
+  if (c->pending > 0 && frame_index != c->pending_first + c->pending) {
+    rc = flush_pending(c);  // non-consecutive index starts a new run: the pending frames claim their slots first
+    if (rc != PQA_OK) return rc;
+  }
+  // before anything is packed (the caller can collect and retry): against the claimed slots, and against the frames still
+  // pending in this run (consecutive indices: they collide only when the run is as long as the ring)
+  rc = check_slots_free(c, frame_index, 1);
   if (rc != PQA_OK) return rc;
   if (c->pending >= c->capacity)
     return fail(c, PQA_ESTATE, "more pending frames than result_capacity %d", c->capacity);
   rc = ensure_staging(c);
   if (rc != PQA_OK) return rc;
-  if (c->pending > 0 && frame_index != c->pending_first + c->pending) {
-    rc = flush_pending(c);  // non-consecutive index starts a new run
-    if (rc != PQA_OK) return rc;
-  }
   Half& H = c->half[c->cur_half];
   if (c->pending == 0) {
     c->pending_first = frame_index;

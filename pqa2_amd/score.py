@@ -15,6 +15,21 @@ import sys
 import time
 
 
+def _die_with_parent() -> None:
+    """A worker must not outlive the job that started it (a rank blocked in the record gather holds its GPU context for
+    ever): ask the kernel for SIGTERM when the parent -- torchrun's agent, or the analyzer for a one-rank job -- goes away.
+    Linux only (prctl PR_SET_PDEATHSIG); elsewhere a no-op."""
+    try:
+        import ctypes
+        import signal
+        libc = ctypes.CDLL(None, use_errno=True)
+        libc.prctl(1, int(signal.SIGTERM), 0, 0, 0)   # PR_SET_PDEATHSIG = 1
+        if os.getppid() == 1:                          # the parent was already gone when we asked
+            os.kill(os.getpid(), signal.SIGTERM)
+    except Exception:
+        pass
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="pqa2_amd.score")
     ap.add_argument("reference")
@@ -34,6 +49,7 @@ def main(argv=None) -> int:
 
     from . import report
     from .pipeline import score_files
+    _die_with_parent()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -75,6 +75,49 @@ except Exception:
             pass
 
 
+# Child jobs (torchrun agent + one worker per GPU) run in their own session so that a stop reaches the whole group; the
+# price is that a Ctrl-C / SIGTERM aimed at THIS process no longer reaches them.  Every live child is therefore registered
+# here: an atexit hook and, where nothing else has claimed them, SIGTERM / SIGINT handlers stop the groups before this
+# process goes (the workers also ask the kernel for SIGTERM on parent death, pqa2_amd/score.py).
+_LIVE_CHILDREN = set()
+_HOOKS_INSTALLED = False
+
+
+def _stop_live_children():
+    for proc in list(_LIVE_CHILDREN):
+        try:
+            VMAFAnalyzer._stop_child(proc, grace=1.0)
+        except Exception:
+            pass
+        _LIVE_CHILDREN.discard(proc)
+
+
+def _install_child_hooks():
+    global _HOOKS_INSTALLED
+    if _HOOKS_INSTALLED:
+        return
+    _HOOKS_INSTALLED = True
+    import atexit
+    import signal
+    import threading
+    atexit.register(_stop_live_children)
+    if threading.current_thread() is not threading.main_thread():
+        return                                  # signal handlers can only be set from the main thread
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            prev = signal.getsignal(sig)
+            if prev not in (signal.SIG_DFL, signal.default_int_handler):
+                continue                        # the application has its own handler: leave it alone (atexit still runs)
+
+            def handler(signum, frame, _prev=prev):
+                _stop_live_children()
+                signal.signal(signum, _prev)    # then what would have happened anyway
+                os.kill(os.getpid(), signum)
+            signal.signal(sig, handler)
+        except Exception:
+            pass
+
+
 class VMAFAnalyzer(QObject):
     """VMAF analyzer for measuring video quality with signals for UI integration."""
     analysis_progress = pyqtSignal(int)   # 0-100%
@@ -340,8 +383,10 @@ class VMAFAnalyzer(QObject):
         state = {"t": time.time()}
         stderr_lines = []
         try:
+            _install_child_hooks()
             self._current_process = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
                                                      bufsize=1, env=env, start_new_session=True)
+            _LIVE_CHILDREN.add(self._current_process)
             for line in iter(self._current_process.stderr.readline, ""):
                 if self._terminate_requested:
                     break
@@ -360,6 +405,7 @@ class VMAFAnalyzer(QObject):
             proc, self._current_process = self._current_process, None
             if proc is not None and proc.poll() is None:
                 self._stop_child(proc, grace=1.0)
+            _LIVE_CHILDREN.discard(proc)
         if self._terminate_requested:
             self._fail("VMAF analysis was terminated by user")
             return False

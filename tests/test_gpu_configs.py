@@ -197,6 +197,44 @@ def test_overwriting_an_uncollected_record_is_estate():
     assert np.array_equal(got.view(np.uint64), full.view(np.uint64))
 
 
+def test_estate_launches_and_loses_nothing():
+    """`PQA_ESTATE: nothing is launched or overwritten` on the two paths that did not keep it.
+    (1) pqa_submit_device with more frames than one batch: a collision in a LATER batch must be found before the first
+    batch is launched.  (2) pqa_submit of a non-consecutive index while earlier frames are still pending: the pending
+    frames are flushed (claim their slots) first, so the check sees them, and they are not dropped."""
+    import torch
+    from pqa2_amd import _native as N
+    from pqa2_amd.engine import FeatureEngine
+    n, w, h = 9, 96, 64
+    refs, diss = _small_clip(n, w, h)
+    R = torch.from_numpy(np.stack([r[0] for r in refs])).cuda()
+    D = torch.from_numpy(np.stack([d[0] for d in diss])).cuda()
+    torch.cuda.synchronize()
+    with FeatureEngine(w, h, max_batch=n, result_capacity=16) as eng:
+        eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [w], [w * h])
+        full = eng.collect(0, n)
+    with FeatureEngine(w, h, max_batch=2, result_capacity=6) as eng:
+        eng.submit_resident(0, 2, [R.data_ptr()], [D.data_ptr()], [w], [w * h])
+        with pytest.raises(N.PqaError) as e:   # frames 4, 5 fit; 6, 7 would land on the uncollected records of 0, 1
+            eng.submit_resident(4, 4, [R[4:].data_ptr()], [D[4:].data_ptr()], [w], [w * h], R[3].data_ptr(), w)
+        assert e.value.code == N.PQA_ESTATE
+        with pytest.raises(N.PqaError) as e:   # ... and the first batch of that call was NOT launched
+            eng.collect(4, 2)
+        assert e.value.code == N.PQA_ESTATE and "never submitted" in str(e.value)
+        assert np.array_equal(eng.collect(0, 2).view(np.uint64), full[:2].view(np.uint64))
+    with FeatureEngine(w, h, max_batch=8, result_capacity=8) as eng:     # host path: 8 frames per staging half
+        for i in range(4):
+            eng.submit(i, refs[i], diss[i])                              # pending, not yet launched
+        with pytest.raises(N.PqaError) as e:
+            eng.submit(8, refs[8], diss[8])                              # slot 0 = frame 0, pending and uncollected
+        assert e.value.code == N.PQA_ESTATE and "uncollected" in str(e.value)
+        assert np.array_equal(eng.collect(0, 4).view(np.uint64), full[:4].view(np.uint64))   # nothing was dropped
+        eng.submit(8, refs[8], diss[8])                                  # and now it fits
+        got8 = eng.collect(8, 1)
+    # frame 8 after a gap: its motion has no predecessor in this context (0), everything else is frame 8's own
+    assert np.array_equal(got8[:, :16].view(np.uint64), full[8:9, :16].view(np.uint64))
+
+
 def test_piecewise_collect_while_later_batches_run():
     """pqa_collect(first, count) waits for the batch that produced those records only (per-batch events): collecting
     batch by batch while the rest of a 1080p clip is still in flight returns exactly the records of one final collect."""
@@ -274,6 +312,58 @@ def test_torchrun_ranks_share_the_gpu_and_match_single_process(tmp_path, ranks, 
     assert _strip_fps(outs["one"][0]) == _strip_fps(outs["many"][0])
     for k in (1, 2):
         assert open(outs["one"][k]).read() == open(outs["many"][k]).read()
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()     # counting devices does not initialise HIP
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: arms itself on a multi-GPU box (the 1-GPU lease skips it)")
+def test_two_ranks_on_rccl_one_gpu_each_match_single_process(tmp_path):
+    """The real N > 1 transport: torchrun, 2 ranks, --backend nccl (= RCCL), one GPU per
+    rank, records all-gathered device to device; JSON (wall-clock `fps` aside), psnr and ssim files byte-equal to the
+    single-process run.  Has never run on the builder's one-GPU lease: it skips there and runs wherever two GPUs exist."""
+    import os
+    import subprocess
+    import sys
+    rp, dp = _write_pair(tmp_path, 320, 180, 11)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for tag, launcher in (("one", []), ("two", ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port())])):
+        j, ps, ss = (str(tmp_path / f"{tag}.{x}") for x in ("json", "psnr", "ssim"))
+        cmd = [sys.executable] + launcher + ["-m", "pqa2_amd.score", rp, dp, "--json", j, "--psnr-log", ps, "--ssim-log", ss,
+                                            "--model", "vmaf_v0.6.1", "--batch", "2"]
+        if launcher:
+            cmd += ["--backend", "nccl"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = (j, ps, ss)
+    assert _strip_fps(outs["one"][0]) == _strip_fps(outs["two"][0])
+    for k in (1, 2):
+        assert open(outs["one"][k]).read() == open(outs["two"][k]).read()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: arms itself on a multi-GPU box (the 1-GPU lease skips it)")
+def test_bench_two_gpus_on_rccl_prints_a_line():
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per GPU, RCCL): one JSON line
+    with n_gpus 2, weak scaling, a whole-job value, and the pooled score of the 2 x F-frame clip equal on repeat runs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "1080p", "--frames", "64"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_total"] == 128 and d["value"] > 0
+    assert 0.0 < d["pooled_vmaf_mean"] <= 100.0
 
 
 def test_analyzer_gpus2_child_job_on_one_gpu(tmp_path):

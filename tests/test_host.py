@@ -277,3 +277,72 @@ def test_committed_kernel_counters_match_the_kernel_source():
     assert e["src_hash"] == bench.kernel_source_hash(), "profiles/kernel_counters.json is stale: re-run tools/profile_round.sh"
     assert e["hbm_bytes_per_frame"] > 2 * 3840 * 2160 and e["valu_wave_insts_per_frame"] > 0
     assert os.path.exists(os.path.join(root, e["traffic_source"].split(" ")[0]))
+
+
+_FAKE_FFMPEG = r'''#!/usr/bin/env python3
+import json, re, sys
+a = sys.argv[1:]
+if "-filters" in a:
+    print("Filters:\n ... lenscorrection      V->V       Rectify the image.\n%s ... libplacebo         N->V       x\n" % LIBVMAF_LINE)
+    sys.exit(0)
+if "-version" in a:
+    print("ffmpeg version 7.1.1-fake Copyright (c) the FFmpeg developers")
+    sys.exit(0)
+opt = a[a.index("-lavfi") + 1]
+assert a[a.index("-i") + 1].endswith("dis.y4m") and "model=version=vmaf_v0.6.1" in opt and "n_subsample=1" in opt, a
+log = re.search(r"log_path=([^:]+)", opt).group(1)
+json.dump({"frames": [{"frameNum": i, "metrics": {"vmaf": 80.0 + i}} for i in range(5)]}, open(log, "w"))
+'''
+
+
+def _fake_ffmpeg(tmp_path, monkeypatch, with_libvmaf):
+    import stat
+    d = tmp_path / "bin"
+    d.mkdir()
+    line = " ... libvmaf            VV->V      Calculate the VMAF between two video streams.\\n" if with_libvmaf else ""
+    f = d / "ffmpeg"
+    f.write_text(_FAKE_FFMPEG.replace("LIBVMAF_LINE", repr(line)))
+    f.chmod(f.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(d) + os.pathsep + os.environ.get("PATH", ""))
+
+
+def test_bench_probes_for_libvmaf_and_runs_the_reference_command_when_it_is_there(tmp_path, monkeypatch):
+    """BASELINE.md section 3 / SURVEY 8(d): bench.py looks for an ffmpeg with the libvmaf filter instead of assuming there is
+    none, and when it finds one it runs the reference's argv (app/vmaf_analyzer.py:411-419: distorted first, model=version=,
+    n_threads, n_subsample) and diffs the log's per-frame vmaf against ours.  A stand-in `ffmpeg` on PATH plays the binary."""
+    import torch
+    import bench
+    _fake_ffmpeg(tmp_path, monkeypatch, with_libvmaf=True)
+    probe = bench.probe_libvmaf()
+    assert probe["ffmpeg_has_libvmaf"] and probe["ffmpeg"].endswith("ffmpeg") and "7.1.1" in probe["ffmpeg_version"]
+    w, h, n = 32, 16, 5
+    ref = [torch.zeros((n, h, w), dtype=torch.uint8)]
+    dis = [torch.ones((n, h, w), dtype=torch.uint8)]
+    ours = np.array([80.0, 81.0, 82.004, 83.0, 84.0])
+    leg = bench._libvmaf_leg(probe, ref, dis, 0, 8, w, h, "vmaf_v0.6.1", ours, n)
+    assert "error" not in leg, leg
+    t4 = leg["n_threads_4"]
+    assert t4["returncode"] == 0 and t4["fps"] > 0 and abs(t4["max_abs_vmaf_diff_per_frame"] - 0.004) < 1e-9
+    assert abs(t4["pooled_abs_vmaf_diff"] - 0.0008) < 1e-9
+
+
+def test_bench_probe_says_no_when_the_filter_is_missing(tmp_path, monkeypatch):
+    import bench
+    _fake_ffmpeg(tmp_path, monkeypatch, with_libvmaf=False)
+    probe = bench.probe_libvmaf()
+    assert probe["ffmpeg"] and not probe["ffmpeg_has_libvmaf"]
+
+
+def test_registered_child_jobs_are_stopped_when_the_process_goes(tmp_path):
+    """ADVICE r2: the torchrun child runs in its own session (so that a stop reaches its whole process group), which also
+    takes it out of reach of a Ctrl-C / SIGTERM aimed at the analyzer's process.  Live children are therefore registered
+    and an atexit / signal hook stops their groups; here the hook body is driven directly on a stand-in child."""
+    import subprocess
+    import sys
+    from pqa2_amd import vmaf_analyzer as va
+    va._install_child_hooks()
+    va._install_child_hooks()                      # idempotent
+    child = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(60)"], start_new_session=True)
+    va._LIVE_CHILDREN.add(child)
+    va._stop_live_children()
+    assert child.poll() is not None and child not in va._LIVE_CHILDREN
