@@ -866,9 +866,11 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
                            MutPlaneRun next_ref, MutPlaneRun next_dis, int s0_mode, int* n_partials) {
   if (n_partials) *n_partials = vif_tiles_x(scale, w) * vif_tiles_y(h);
   if (n_frames <= 0) return hipSuccess;
-  if (scale == 0 && elem == ELEM_U8 && s0_mode == VIF_S0_AUTO && next_ref.base && next_dis.base) {
+  // (10 bit is recognised by its sample scale 1/4; 12-bit clips have squares of 22 bits, three digits: tiled kernels)
+  if (scale == 0 && (elem == ELEM_U8 || (elem == ELEM_U16 && inv_scale == 0.25f)) && s0_mode == VIF_S0_AUTO && next_ref.base &&
+      next_dis.base) {
     hipError_t err = hipSuccess;
-    if (launch_vif_s0_march(stream, ref, dis, n_frames, w, h, gain_limit, border101, partials, next_ref, next_dis, n_partials, &err))
+    if (launch_vif_s0_march(stream, elem, ref, dis, n_frames, w, h, gain_limit, border101, partials, next_ref, next_dis, n_partials, &err))
       return err;
     if (n_partials) *n_partials = vif_tiles_x(scale, w) * vif_tiles_y(h);
   }

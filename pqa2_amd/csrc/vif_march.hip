@@ -71,7 +71,8 @@ enum : int {
   F_VD = 14,   // 14,15  pass 2 of the next scale's input, c' * 2^8, even output rows in N slots 0..7
   F_W = 16,    // 16,17  as F_V with K order {current block rows, previous block rows}
   F_WD = 18,   // 18,19  as F_VD in that order
-  kMarchFrags = 20
+  F_L9 = 20,   // 20,21  pass 1 of 10-bit clips, c * 2^9 in two pieces (low digits base 1024)
+  kMarchFrags = 22
 };
 
 struct MarchArgs {
@@ -80,7 +81,7 @@ struct MarchArgs {
   unsigned pitch_r, pitch_d;               // bytes
   int64_t frame_pitch_r, frame_pitch_d;    // bytes
   int w, h, fold_w, fold_h;
-  int aligned;                             // bases and pitches allow 8-byte loads
+  int aligned;                             // bases and pitches allow one 8-sample load per lane (8 / 16 bytes)
   float gain_limit;
   double* partials;                        // [n_frames][n_part][2]
   int n_part;
@@ -182,7 +183,16 @@ __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2
 #ifndef PQA_MARCH_OCC
 #define PQA_MARCH_OCC (PQA_MARCH_LDS_TABLES ? 3 : 2)
 #endif
+// S = uint8_t: 8-bit samples as described at the top.  S = uint16_t: 10-bit samples (libvmaf: x = v / 4 - 128 = (v - 512) / 4):
+// a sample (<= 1023 < 2048) is again its own f16 pattern, so the mean planes take the loaded dwords as they are; the squares
+// and the cross term of v - 512 (|.| <= 512, products of up to 19 bits) come from 32-bit multiplies and are split into
+// base-1024 digits (hi <= 512, lo < 1024); the low digit planes use pieces of c * 2^9.  Every plane then leaves pass 1 as
+// 2^-13 (means) or 2^-15 (squares) of its integer sum, and the sample scale (1/4 on the means, 1/16 on the squares) joins
+// the split's factor.  12-bit clips (squares of 22 bits: three digits) stay on the tiled kernels.
+template <typename S>
 __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(const MarchArgs a) {
+  constexpr bool W16 = sizeof(S) == 2;
+  constexpr int ES = (int)sizeof(S);
   const int tid = threadIdx.x;
 #if PQA_MARCH_LDS_TABLES
   // fragments F_DR .. F_DD + 2 (6), F_VD, F_VD + 1, F_WD, F_WD + 1 -> LDS slots 0..9
@@ -210,20 +220,21 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   const int ys = rb0 * 16;
   const int m = lane & 15, kq = lane >> 4;
 
-  const uint8_t* __restrict__ ref = (const uint8_t*)a.ref + (int64_t)fr * a.frame_pitch_r;
+  const uint8_t* __restrict__ ref = (const uint8_t*)a.ref + (int64_t)fr * a.frame_pitch_r;   // pitches are in bytes
   const uint8_t* __restrict__ dis = (const uint8_t*)a.dis + (int64_t)fr * a.frame_pitch_d;
   const auto rsrc_r = make_rsrc(ref, (unsigned)a.h * a.pitch_r);
   const auto rsrc_d = make_rsrc(dis, (unsigned)a.h * a.pitch_d);
   // all 32 input columns of the stripe inside the image and 8-byte loads allowed: one load per lane and image
   const bool colfast = a.aligned && x0 - 8 >= 0 && x0 + 24 <= a.w;   // wave-uniform
-  const int xin = x0 - 8 + 8 * kq;                                    // this lane's first input column
+  const int xin = x0 - 8 + 8 * kq;                                    // this lane's first input column (samples)
 
   // tap-matrix fragments of this lane
   h8 T[kMarchFrags];
 #pragma unroll
   for (int f = 0; f < kMarchFrags; ++f) {
-    const bool in_lds = PQA_MARCH_LDS_TABLES && ((f >= F_DR && f < F_DR + 6) || (f >= F_VD && f < F_VD + 2) || f >= F_WD);
-    if (!in_lds) T[f] = __builtin_bit_cast(h8, a.tab[f * 64 + lane]);
+    const bool in_lds = PQA_MARCH_LDS_TABLES && ((f >= F_DR && f < F_DR + 6) || (f >= F_VD && f < F_VD + 2) || (f >= F_WD && f < F_WD + 2));
+    const bool unused = W16 ? false : f >= F_L9;
+    if (!in_lds && !unused) T[f] = __builtin_bit_cast(h8, a.tab[f * 64 + lane]);
   }
 #if PQA_MARCH_LDS_TABLES
   // a fragment kept in LDS, read where it is used.  The lane's byte offset goes through an empty asm once per pass (tab_off,
@@ -243,46 +254,69 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   // ---- loads: 8 consecutive samples of row (block row m) per image ----------------------------------------------
   // A block whose 16 rows lie inside the image needs no per-lane row arithmetic at all: the lane part of the address
   // (m * pitch + first column) is fixed for the whole march and the block's first row goes into the load's SCALAR offset.
-  const unsigned lane_off_r = (unsigned)m * a.pitch_r + (unsigned)xin, lane_off_d = (unsigned)m * a.pitch_d + (unsigned)xin;
-  const auto load_block = [&](int rb, u2v& R, u2v& D) {
+  const unsigned lane_off_r = (unsigned)m * a.pitch_r + (unsigned)(xin * ES), lane_off_d = (unsigned)m * a.pitch_d + (unsigned)(xin * ES);
+  // R / D: the lane's 8 samples, packed as they lie in memory (8 bit: dwords 0, 1; 10 bit: dwords 0..3)
+  const auto load8 = [&](const rsrc_t rs, const unsigned voff, const unsigned soff) -> u4v {
+    if (W16) return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    const u2v v = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+    return u4v{v[0], v[1], 0u, 0u};
+  };
+  const auto load_block = [&](int rb, u4v& R, u4v& D) {
     const int y_first = ys - 8 + 16 * rb;                                 // wave-uniform
     const bool rows_in = y_first >= 0 && y_first + 16 <= a.h;
     if (colfast && rows_in) {
-      R = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, lane_off_r, (unsigned)y_first * a.pitch_r, 0));
-      D = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, lane_off_d, (unsigned)y_first * a.pitch_d, 0));
+      R = load8(rsrc_r, lane_off_r, (unsigned)y_first * a.pitch_r);
+      D = load8(rsrc_d, lane_off_d, (unsigned)y_first * a.pitch_d);
       return;
     }
     const unsigned my = (unsigned)mirror_fold(y_first + m, a.h, a.fold_h);
     if (colfast) {
-      R = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, my * a.pitch_r + (unsigned)xin, 0, 0));
-      D = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, my * a.pitch_d + (unsigned)xin, 0, 0));
-    } else {   // stripes at the left / right image edge (mirrored columns) or unaligned planes: byte by byte
+      R = load8(rsrc_r, my * a.pitch_r + (unsigned)(xin * ES), 0);
+      D = load8(rsrc_d, my * a.pitch_d + (unsigned)(xin * ES), 0);
+    } else {   // stripes at the left / right image edge (mirrored columns) or unaligned planes: sample by sample
       unsigned r[8], d[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const unsigned mx = (unsigned)mirror_fold(xin + j, a.w, a.fold_w);
-        r[j] = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, my * a.pitch_r + mx, 0, 0) & 0xffu;
-        d[j] = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, my * a.pitch_d + mx, 0, 0) & 0xffu;
+        const unsigned mx = (unsigned)mirror_fold(xin + j, a.w, a.fold_w) * ES;
+        if (W16) {
+          r[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_r, my * a.pitch_r + mx, 0, 0);
+          d[j] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc_d, my * a.pitch_d + mx, 0, 0);
+        } else {
+          r[j] = __builtin_amdgcn_raw_buffer_load_b8(rsrc_r, my * a.pitch_r + mx, 0, 0) & 0xffu;
+          d[j] = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, my * a.pitch_d + mx, 0, 0) & 0xffu;
+        }
       }
-      R = u2v{r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24)};
-      D = u2v{d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24), d[4] | (d[5] << 8) | (d[6] << 16) | (d[7] << 24)};
+      if (W16) {
+        R = u4v{r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16)};
+        D = u4v{d[0] | (d[1] << 16), d[2] | (d[3] << 16), d[4] | (d[5] << 16), d[6] | (d[7] << 16)};
+      } else {
+        R = u4v{r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24), 0u, 0u};
+        D = u4v{d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24), d[4] | (d[5] << 8) | (d[6] << 16) | (d[7] << 24), 0u, 0u};
+      }
     }
   };
 
   // ---- pass 1 + split: one 16 x 32 input block -> this lane's pieces -----------------------------------------------
-  const auto pass1 = [&](const u2v R, const u2v D, Pieces& P, auto half) {
+  const auto pass1 = [&](const u4v R, const u4v D, Pieces& P, auto half) {
     constexpr int H = decltype(half)::value;
     TD_REFRESH();
     const f4 z = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    // 16-bit lanes {col 2v, col 2v+1} of this lane's 8 columns: byte -> zero-extended half (one v_perm_b32 each)
-    unsigned ru[4], du[4], r16[4], d16[4], t[4];
+    // 16-bit lanes {col 2v, col 2v+1} of this lane's 8 columns.  8 bit: byte -> zero-extended half (one v_perm_b32 each);
+    // 10 bit: the loaded dwords as they are.  r16 / d16: the same minus mid-grey, as signed 16-bit integers.
+    constexpr short MID = W16 ? 512 : 128;
+    unsigned ru[4], du[4], r16[4], d16[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const unsigned sel = (v & 1) ? 0x0c030c02u : 0x0c010c00u;
-      ru[v] = __builtin_amdgcn_perm(0u, R[v >> 1], sel);
-      du[v] = __builtin_amdgcn_perm(0u, D[v >> 1], sel);
-      r16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, ru[v]) - s2v{128, 128});
-      d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{128, 128});
+      if (W16) {
+        ru[v] = R[v];
+        du[v] = D[v];
+      } else {
+        const unsigned sel = (v & 1) ? 0x0c030c02u : 0x0c010c00u;
+        ru[v] = __builtin_amdgcn_perm(0u, R[v >> 1], sel);
+        du[v] = __builtin_amdgcn_perm(0u, D[v >> 1], sel);
+      }
+      r16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, ru[v]) - s2v{MID, MID});
+      d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{MID, MID});
     }
     f4 Dh[5], Dd;
     {  // means and the next scale's input: the SAMPLES themselves (k * 2^-24); the mid-grey term 128 * sum(taps) is a constant
@@ -299,44 +333,57 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
       Dh[1] = mma(A, T[F_LO + 2], Dh[1]); Dd = mma(A, TD(F_DD + 2), Dd);
     }
 #pragma unroll
-    for (int s = 2; s < 5; ++s) {   // r'^2, d'^2, r'd': exact 16-bit integer products, digits base 256
-      unsigned q[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const s2v x = __builtin_bit_cast(s2v, s == 3 ? d16[v] : r16[v]);
-        const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
-        // the cross term is signed: + 64 * 256 makes both digits unsigned (one v_pk_mad_u16), the 64 comes off below
-        q[v] = __builtin_bit_cast(unsigned, s == 4 ? (s2v)(x * y + s2v{0x4000, 0x4000}) : (s2v)(x * y));
-      }
-      {  // low digit: byte 0 of each 16-bit product
-#pragma unroll
-        for (int v = 0; v < 4; ++v) t[v] = __builtin_amdgcn_perm(0u, q[v], 0x0c020c00u);
-        const h8 A = frag4(t[0], t[1], t[2], t[3]);
-        Dh[s] = mma(A, T[F_LO], z);
-        Dh[s] = mma(A, T[F_LO + 1], Dh[s]);
-      }
-      {  // high digit: byte 1
+    for (int s = 2; s < 5; ++s) {   // r'^2, d'^2, r'd': exact integer products, split into two digits
+      unsigned lo_[4], hi_[4];
+      if (!W16) {   // 16-bit products, digits base 256
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          t[v] = __builtin_amdgcn_perm(0u, q[v], 0x0c030c01u);
-          if (s == 4) t[v] = tiny_minus(t[v], 0x8040);   // - 64 * 2^-24
+          const s2v x = __builtin_bit_cast(s2v, s == 3 ? d16[v] : r16[v]);
+          const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
+          // the cross term is signed: + 64 * 256 makes both digits unsigned (one v_pk_mad_u16), the 64 comes off below
+          const unsigned q = __builtin_bit_cast(unsigned, s == 4 ? (s2v)(x * y + s2v{0x4000, 0x4000}) : (s2v)(x * y));
+          lo_[v] = __builtin_amdgcn_perm(0u, q, 0x0c020c00u);   // byte 0 of each 16-bit product
+          hi_[v] = __builtin_amdgcn_perm(0u, q, 0x0c030c01u);   // byte 1
+          if (s == 4) hi_[v] = tiny_minus(hi_[v], 0x8040);      // - 64 * 2^-24
         }
-        const h8 A = frag4(t[0], t[1], t[2], t[3]);
+      } else {      // |v - 512| <= 512: 32-bit products of the sign-extended halves, digits base 1024; the cross term gets
+                    // 256 * 1024 added so that its high digit (in [0, 512]) is unsigned like the squares'
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const unsigned xs = s == 3 ? d16[v] : r16[v], ys = s == 2 ? r16[v] : d16[v];
+          const int x0_ = (int)(short)(xs & 0xffffu), x1_ = (int)xs >> 16;
+          const int y0_ = (int)(short)(ys & 0xffffu), y1_ = (int)ys >> 16;
+          const int add = s == 4 ? (256 << 10) : 0;
+          const unsigned p0 = (unsigned)(x0_ * y0_ + add), p1 = (unsigned)(x1_ * y1_ + add);
+          lo_[v] = ((p1 << 16) & 0x03ff0000u) | (p0 & 0x3ffu);
+          const unsigned hgh = ((p1 << 6) & 0xffff0000u) | (p0 >> 10);
+          hi_[v] = s == 4 ? tiny_minus(hgh, 0x8100) : hgh;       // - 256 * 2^-24
+        }
+      }
+      {
+        const h8 A = frag4(lo_[0], lo_[1], lo_[2], lo_[3]);
+        Dh[s] = mma(A, T[W16 ? F_L9 : F_LO], z);
+        Dh[s] = mma(A, T[W16 ? F_L9 + 1 : F_LO + 1], Dh[s]);
+      }
+      {
+        const h8 A = frag4(hi_[0], hi_[1], hi_[2], hi_[3]);
         Dh[s] = mma(A, T[F_HI], Dh[s]);
         Dh[s] = mma(A, T[F_HI + 1], Dh[s]);
         Dh[s] = mma(A, T[F_HI + 2], Dh[s]);
       }
     }
-    // pass 1 leaves every signal times 2^-13 and the next scale's input times 2^-6 (operands k * 2^-24, pieces of
-    // c * 2^11, c * 2^19 on the digits that weigh 2^8, c' * 2^18).  Into pass 2: means as natural / 16, squares as natural,
-    // the next scale's input as natural.
+    // pass 1 leaves every signal of an 8-bit clip times 2^-13 and the next scale's input times 2^-6 (operands k * 2^-24,
+    // pieces of c * 2^11, c * 2^19 on the digits that weigh 2^8, c' * 2^18); for 10-bit clips the means again times 2^-13
+    // and the squares times 2^-15 (base-1024 digits, low pieces c * 2^9), both still in sample units (x 4 and x 16).
+    // Into pass 2: means as natural / 16, squares as natural, the next scale's input as natural.
     // The means were filtered as samples: sum c (x - 128) = sum c x - 128 sum c, with sum c the exact sum of the f32 taps.
-    split4<H>(Dh[0], 512.0f, a.mean_off, P.hi[0], P.lo[0]);
-    split4<H>(Dh[1], 512.0f, a.mean_off, P.hi[1], P.lo[1]);
-    split4<H>(Dh[2], 8192.0f, 0.0f, P.hi[2], P.lo[2]);
-    split4<H>(Dh[3], 8192.0f, 0.0f, P.hi[3], P.lo[3]);
-    split4<H>(Dh[4], 8192.0f, 0.0f, P.hi[4], P.lo[4]);
-    split4<H>(Dd, 64.0f, a.dec_off, P.hi[5], P.lo[5]);
+    constexpr float KM = W16 ? 128.0f : 512.0f, KS = W16 ? 2048.0f : 8192.0f, KD = W16 ? 16.0f : 64.0f;
+    split4<H>(Dh[0], KM, a.mean_off, P.hi[0], P.lo[0]);
+    split4<H>(Dh[1], KM, a.mean_off, P.hi[1], P.lo[1]);
+    split4<H>(Dh[2], KS, 0.0f, P.hi[2], P.lo[2]);
+    split4<H>(Dh[3], KS, 0.0f, P.hi[3], P.lo[3]);
+    split4<H>(Dh[4], KS, 0.0f, P.hi[4], P.lo[4]);
+    split4<H>(Dd, KD, a.dec_off, P.hi[5], P.lo[5]);
   };
 
   double dnum = 0.0, dden = 0.0;
@@ -405,22 +452,22 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   for (int i = 0; i < 6; ++i) { P.hi[i] = u4v{0u, 0u, 0u, 0u}; P.lo[i] = u4v{0u, 0u, 0u, 0u}; }
   const std::integral_constant<int, 0> even{};
   const std::integral_constant<int, 1> odd{};
-  u2v Rn, Dn;
+  u4v Rn, Dn;
   load_block(0, Rn, Dn);
   {
-    const u2v Rc = Rn, Dc = Dn;
+    const u4v Rc = Rn, Dc = Dn;
     load_block(1, Rn, Dn);   // n_out >= 1: block 1 always exists
     pass1(Rc, Dc, P, even);
   }
   for (int rb = 1; rb <= n_out; rb += 2) {
     {   // odd block -> upper half; window (lower half older, upper half newer)
-      const u2v Rc = Rn, Dc = Dn;
+      const u4v Rc = Rn, Dc = Dn;
       if (rb < n_out) load_block(rb + 1, Rn, Dn);   // in flight while this block is computed
       pass1(Rc, Dc, P, odd);
       pass2(P, F_V, F_VD, ys + 16 * (rb - 1));
     }
     if (rb + 1 <= n_out) {   // even block -> lower half; window (lower half newer, upper half older)
-      const u2v Rc = Rn, Dc = Dn;
+      const u4v Rc = Rn, Dc = Dn;
       if (rb + 1 < n_out) load_block(rb + 2, Rn, Dn);
       pass1(Rc, Dc, P, even);
       pass2(P, F_W, F_WD, ys + 16 * rb);
@@ -472,6 +519,7 @@ bool build_table(uint16_t* out /* [kMarchFrags][64][8] */) {
       const double c = (t >= 0 && t <= 16) ? (double)c17[t] : 0.0;
       if (pieces(c * 524288.0, 3, o + F_HI * stride, stride) != 0.0) exact = false;
       if (pieces(c * 2048.0, 3, o + F_LO * stride, stride) != 0.0) exact = false;
+      pieces(c * 512.0, 2, o + F_L9 * stride, stride);   // the 10-bit low digits weigh 2^-10 of the signal: 22 bits of the tap
       // next scale: N slot n = even column 2 (n & 7) (window column 2 (n & 7) + 8) of ref (n < 8) or dis (n >= 8)
       const int t9 = wc - (2 * (n & 7) + 4);
       const double cd = (t9 >= 0 && t9 <= 8) ? (double)c9[t9] : 0.0;
@@ -532,20 +580,22 @@ hipError_t vif_march_prepare() {
   return hipSuccess;
 }
 
-bool launch_vif_s0_march(hipStream_t stream, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
+bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
                          int border101, double* partials, MutPlaneRun next_ref, MutPlaneRun next_dis, int* n_partials,
                          hipError_t* err) {
   MarchArgs a{};
   a.tab = device_tab();
   if (!a.tab) return false;
-  if (ref.row_pitch >= (1ll << 31) || dis.row_pitch >= (1ll << 31)) return false;
+  if (elem != ELEM_U8 && elem != ELEM_U16) return false;
+  const int es = elem == ELEM_U16 ? 2 : 1;
+  if (ref.row_pitch * es >= (1ll << 31) || dis.row_pitch * es >= (1ll << 31)) return false;
   a.ref = ref.base; a.dis = dis.base;
-  a.pitch_r = (unsigned)ref.row_pitch; a.pitch_d = (unsigned)dis.row_pitch;
-  a.frame_pitch_r = ref.frame_pitch; a.frame_pitch_d = dis.frame_pitch;
+  a.pitch_r = (unsigned)(ref.row_pitch * es); a.pitch_d = (unsigned)(dis.row_pitch * es);
+  a.frame_pitch_r = ref.frame_pitch * es; a.frame_pitch_d = dis.frame_pitch * es;
   a.w = w; a.h = h;
   a.fold_w = 2 * w - (border101 ? 2 : 1); a.fold_h = 2 * h - (border101 ? 2 : 1);
-  a.aligned = (((uintptr_t)ref.base | (uintptr_t)dis.base | (uintptr_t)ref.row_pitch | (uintptr_t)dis.row_pitch |
-                (uintptr_t)ref.frame_pitch | (uintptr_t)dis.frame_pitch) & 7) == 0;
+  a.aligned = (((uintptr_t)ref.base | (uintptr_t)dis.base | (uintptr_t)a.pitch_r | (uintptr_t)a.pitch_d |
+                (uintptr_t)a.frame_pitch_r | (uintptr_t)a.frame_pitch_d) & (uintptr_t)(8 * es - 1)) == 0;
   a.gain_limit = gain_limit;
   a.partials = partials;
   a.dst_ref = (float*)next_ref.base; a.dst_dis = (float*)next_dis.base;
@@ -581,7 +631,8 @@ bool launch_vif_s0_march(hipStream_t stream, PlaneRun ref, PlaneRun dis, int n_f
   a.n_seg = (a.row_blocks + seg - 1) / seg;
   a.n_part = a.n_cbg * 4 * a.n_seg;
   if (n_partials) *n_partials = a.n_part;
-  hipLaunchKernelGGL(vif_s0_march_kernel, dim3(a.n_cbg * a.n_seg, n_frames), dim3(kBlock), 0, stream, a);
+  if (elem == ELEM_U16) hipLaunchKernelGGL(vif_s0_march_kernel<uint16_t>, dim3(a.n_cbg * a.n_seg, n_frames), dim3(kBlock), 0, stream, a);
+  else hipLaunchKernelGGL(vif_s0_march_kernel<uint8_t>, dim3(a.n_cbg * a.n_seg, n_frames), dim3(kBlock), 0, stream, a);
   *err = hipGetLastError();
   return true;
 }

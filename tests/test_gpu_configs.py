@@ -438,12 +438,12 @@ def test_rccl_gather_of_device_records_with_one_rank(tmp_path):
 @pytest.mark.parametrize("w,h,bpc", [(488, 40, 8), (489, 41, 8), (736, 48, 8), (1000, 200, 8), (1281, 721, 8), (1920, 1080, 8),
                                      (64, 48, 10), (489, 41, 10), (1000, 200, 10), (1920, 1080, 10)])
 def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
-    """Scale 0 on the matrix cores against the VALU kernel and the oracle.  8 bit: the march kernel (vif_march.hip: first
-    pass on exact integer digit planes x three-piece taps, second pass on two-piece f16 splits of the f32 intermediates);
-    10 bit: the round-2 kernel (vertical pass on the matrix cores).  Geometries from 64 x 48 up to 1080p, odd sizes
-    included.  The paths must agree far inside the oracle bar, PQA_VIF_MFMA=0 (read at pqa_create) must really switch the
-    path off, PQA_VIF_MFMA=2 must give the round-2 kernel, and a caller pitch the wide loads cannot take (odd) must not
-    change a bit: the march kernel then loads byte by byte, the round-2 kernel hands over to the VALU kernel."""
+    """Scale 0 on the matrix cores against the VALU kernel and the oracle: the march kernel (vif_march.hip: first pass on
+    exact integer digit planes x three-piece taps, second pass on two-piece f16 splits of the f32 intermediates), 8 and 10
+    bit.  Geometries from 64 x 48 up to 1080p, odd sizes included.  The paths must agree far inside the oracle bar,
+    PQA_VIF_MFMA=0 (read at pqa_create) must really switch the path off, PQA_VIF_MFMA=2 must give the round-2 kernel
+    (vertical pass on the matrix cores only), and a caller pitch the wide loads cannot take (odd) must not change a bit:
+    the march kernel then loads sample by sample."""
     import os
     import torch
     from pqa2_amd import synth
@@ -484,7 +484,7 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
     assert rel.max() < 2e-6, rel.max()
     assert (np.abs(mfma101 - valu101) / np.abs(valu101)).max() < 2e-6
     assert (np.abs(split - valu) / np.abs(valu)).max() < 2e-6
-    if bpc == 8 and w >= 488 and h >= 40:    # the round-2 kernel is a different kernel from the march kernel (and needs one interior pair)
+    if w >= 488 and h >= 40:    # the round-2 kernel is a different kernel from the march kernel (and needs one interior pair)
         assert not np.array_equal(split.view(np.uint64), mfma.view(np.uint64))
     assert np.all(np.isfinite(mfma))
     exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc)[:, :8]
@@ -502,7 +502,7 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
         with FeatureEngine(w, h, bit_depth=bpc, features=N.FEAT_VIF) as eng:
             eng.submit_resident(0, n, [R.data_ptr()], [D.data_ptr()], [pitch * es], [pitch * h * es])
             odd = eng.collect(0, n)[:, :8]
-        assert np.array_equal(odd.view(np.uint64), (mfma if bpc == 8 else valu).view(np.uint64))
+        assert np.array_equal(odd.view(np.uint64), mfma.view(np.uint64))
 
 
 def test_worst_known_hd_flip_case_stays_bounded():
