@@ -143,7 +143,8 @@ struct Pieces {
 // vif_statistic_s on two horizontally adjacent pixels, in units U = 16 (see the file comment): accumulates the low-branch
 // sums and the three log products.  Same algebra as vif_hstat (vif.hip), which documents each override that drops out.
 struct StatAcc {
-  f2 num2, den2, pn, qn, pd;
+  f2 num2, pn, qn, pd;
+  int n_low;   // pixels on the low-variance branch: den_val = 1 each, counted with scalar popcounts (wave-uniform)
 };
 __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2, const f2 xx, const f2 yy, const f2 xy,
                                           const bool v0, const bool v1, const float gain_limit) {
@@ -152,8 +153,11 @@ __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2
   f2 s2 = yy - mu2 * mu2;
   const f2 s12 = xy - mu1 * mu2;
   s2 = f2{fmaxf(s2.x, 0.0f), fmaxf(s2.y, 0.0f)};
-  const bool hx = v0 && !(s1.x < sigma_nsq), hy = v1 && !(s1.y < sigma_nsq);
-  const bool lx = v0 && (s1.x < sigma_nsq), ly = v1 && (s1.y < sigma_nsq);
+  // ONE compare per pixel: "low" = sigma1_sq < sigma_nsq (a NaN cannot occur: every input is a finite filter output); the
+  // branch masks are lane masks in SGPRs, combined with the validity masks by scalar instructions
+  const bool lt0 = s1.x < sigma_nsq, lt1 = s1.y < sigma_nsq;
+  const bool hx = v0 && !lt0, hy = v1 && !lt1;
+  const bool lx = v0 && lt0, ly = v1 && lt1;
   const f2 s1h = f2{hx ? s1.x : 0.0f, hy ? s1.y : 0.0f};
   const f2 gden = s1h + f2{eps, eps};
   const f2 grcp = f2{fast_rcp(gden.x), fast_rcp(gden.y)};
@@ -169,9 +173,9 @@ __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2
   s.pn *= narg;
   s.qn *= svn;
   s.pd *= darg;
-  const f2 wl = f2{lx ? 1.0f : 0.0f, ly ? 1.0f : 0.0f};
-  s.num2 = __builtin_elementwise_fma(wl, low, s.num2);
-  s.den2 += wl;
+  s.num2 += f2{lx ? low.x : 0.0f, ly ? low.y : 0.0f};
+  // den_val = 1 per low pixel: the wave's count of them is a popcount of the lane mask -- scalar unit, no VALU work
+  s.n_low += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lx)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(ly));
 }
 
 // PQA_MARCH_LDS_TABLES: the tap fragments of the next scale's input (used once per block each) stay in LDS and are read
@@ -387,6 +391,7 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   };
 
   double dnum = 0.0, dden = 0.0;
+  int n_low_wave = 0;   // wave-uniform (scalar) count of low-branch pixels: each contributes den_val = 1
   // validity of this lane's four output columns (wave-uniform per K group, constant over the march)
   bool vcol[4];
 #pragma unroll
@@ -432,15 +437,16 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
     }
     // statistic on this lane's 4 pixels (row yo + m, columns x0 + 4 kq + i)
     const bool vrow = yo + m < a.h;
-    StatAcc st{f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}};
+    StatAcc st{f2{0.0f, 0.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, 0};
     stat_pair(st, f2{V[0][0], V[0][1]}, f2{V[1][0], V[1][1]}, f2{V[2][0], V[2][1]}, f2{V[3][0], V[3][1]},
               f2{V[4][0], V[4][1]}, vrow && vcol[0], vrow && vcol[1], a.gain_limit);
     stat_pair(st, f2{V[0][2], V[0][3]}, f2{V[1][2], V[1][3]}, f2{V[2][2], V[2][3]}, f2{V[3][2], V[3][3]},
               f2{V[4][2], V[4][3]}, vrow && vcol[2], vrow && vcol[3], a.gain_limit);
     const float num = (st.num2.x + st.num2.y) + ((fast_log2(st.pn.x) - fast_log2(st.qn.x)) + (fast_log2(st.pn.y) - fast_log2(st.qn.y)));
-    const float den = (st.den2.x + st.den2.y) + (fast_log2(st.pd.x) + fast_log2(st.pd.y));
+    const float den = fast_log2(st.pd.x) + fast_log2(st.pd.y);
     dnum += (double)num;
     dden += (double)den;
+    n_low_wave += st.n_low;
   };
 
   // Blocks alternate between the two halves of the operand vectors: the even blocks live in dwords {0, 1}, the odd ones in
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   }
   dnum = wave_sum(dnum);
   dden = wave_sum(dden);
-  if (lane == 0) { part[0] = dnum; part[1] = dden; }
+  if (lane == 0) { part[0] = dnum; part[1] = dden + (double)n_low_wave; }
 }
 
 // ---- host: the per-lane tap-matrix fragments ------------------------------------------------------------------------
