@@ -276,7 +276,7 @@ def main():
                     n_cb, rbk = (w + 15) // 16, (h + 15) // 16
                     n_cbg = (n_cb + 3) // 4
                     seg = rbk
-                    while seg > 8 and n_cbg * 4 * ((rbk + seg - 1) // seg) * args.batch < 16 * 3072:
+                    while seg > 8 and n_cbg * 4 * ((rbk + seg - 1) // seg) < 1536:
                         seg = (seg + 1) // 2
                     seg = max(seg, min(rbk, 8))
                     n_seg = (rbk + seg - 1) // seg

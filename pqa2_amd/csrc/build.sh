@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 OBJS=()
 PIDS=()
 for f in vif vif_march vif_fixed adm adm_fixed motion motion_fixed psnr_ssim luma_stats finalize ingest pqa_api; do
-  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ kernels.h -nt "$f.o" ] || [ pqa_device.h -nt "$f.o" ] || [ ingest.h -nt "$f.o" ] || [ ../../include/pqa_vmaf.h -nt "$f.o" ]; then
+  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ kernels.h -nt "$f.o" ] || [ pqa_device.h -nt "$f.o" ] || [ march_common.h -nt "$f.o" ] || [ ingest.h -nt "$f.o" ] || [ ../../include/pqa_vmaf.h -nt "$f.o" ]; then
     rm -f "$f.o"   # a failed compile must not leave a stale object for the link step
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
     PIDS+=("$!")

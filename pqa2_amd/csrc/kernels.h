@@ -110,7 +110,6 @@ inline int motion_tiles(int w, int h) {
 // `prev0` (may be null: then its partials are zero).  partials: [n_frames][tiles] doubles.
 hipError_t launch_motion(hipStream_t stream, Elem elem, PlaneRun ref, const void* prev0, int64_t prev0_row_pitch,
                          int n_frames, int w, int h, float inv_scale, double* partials);
-
 // Fixed-point motion (integer_motion.c arithmetic, motion_fixed.hip): partials are [n_frames][tiles] uint64 SADs of
 // the Q8 blurred planes.
 hipError_t launch_motion_fixed(hipStream_t stream, int bit_depth, Elem elem, PlaneRun ref, const void* prev0,

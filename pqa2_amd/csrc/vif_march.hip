@@ -49,17 +49,14 @@
 #include <vector>
 
 #include "kernels.h"
+#include "march_common.h"
 #include "pqa_device.h"
 
 namespace pqa {
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef short s2v __attribute__((ext_vector_type(2)));
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
+using namespace march;
 
 // fragments of the per-lane tap table (each: 64 lanes x 8 f16)
 enum : int {
@@ -94,45 +91,6 @@ struct MarchArgs {
   const uint4* tab;
 };
 
-__device__ __forceinline__ h8 frag4(unsigned a, unsigned b, unsigned c, unsigned d) {
-  return __builtin_bit_cast(h8, u4v{a, b, c, d});
-}
-// two integers k < 2048 (one per 16-bit half) -> two f16 (k - off) * 2^-24, exact; off_bits = off as f16 bits | 0x8000
-__device__ __forceinline__ unsigned tiny_minus(unsigned x, unsigned short off_bits) {
-  const h2 o = __builtin_bit_cast(h2, (unsigned)off_bits | ((unsigned)off_bits << 16));
-  return __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, x) + o);
-}
-__device__ __forceinline__ f4 mma(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-
-// v - hi for a value v and its f16 rounding hi (one half of a packed pair): exact in f32 (hi shares v's leading bits).
-// v_fma_mix_f32 reads the f16 half in place -- no conversion instruction, one VALU op per value.
-template <int HALF>
-__device__ __forceinline__ float residual(const unsigned hi_pair, const float v) {
-  float r;
-  if (HALF == 0)
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pair), "s"(-1.0f), "v"(v));
-  else
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pair), "s"(-1.0f), "v"(v));
-  return r;
-}
-
-// Four f32 values v * s + b (s an exact power of two; b removes the mid-grey term of the mean planes, see pass1) -> two
-// f16 pieces each: hi = rne(x), lo = rne(x - hi).
-// hi / lo: {piece(x0), piece(x1)}, {piece(x2), piece(x3)} -- the element order of an MFMA operand.
-template <int HALF>   // which half of the operand vectors (0: dwords 0, 1; 1: dwords 2, 3) receives the pieces
-__device__ __forceinline__ void split4(const f4 v, const float s, const float b, u4v& hi, u4v& lo) {
-  const f2 xa = __builtin_elementwise_fma(f2{v[0], v[1]}, f2{s, s}, f2{b, b});
-  const f2 xb = __builtin_elementwise_fma(f2{v[2], v[3]}, f2{s, s}, f2{b, b});
-  const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(xa, h2));
-  const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(xb, h2));
-  const f2 ra = f2{residual<0>(h0, xa[0]), residual<1>(h0, xa[1])};
-  const f2 rb = f2{residual<0>(h1, xb[0]), residual<1>(h1, xb[1])};
-  hi[2 * HALF] = h0;
-  hi[2 * HALF + 1] = h1;
-  lo[2 * HALF] = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, h2));
-  lo[2 * HALF + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(rb, h2));
-}
-
 // The pieces of TWO consecutive 16-row blocks after pass 1 (rows 4 (lane >> 4) + i of column (lane & 15)), laid out as the
 // pass-2 operands themselves: dwords {0, 1} of each vector belong to the even block, {2, 3} to the odd one.  Plane 5 is
 // the next scale's input (N slot (lane & 15) = even column of ref (0..7) / dis (8..15)).
@@ -143,8 +101,7 @@ struct Pieces {
 // vif_statistic_s on two horizontally adjacent pixels, in units U = 16 (see the file comment): accumulates the low-branch
 // sums and the three log products.  Same algebra as vif_hstat (vif.hip), which documents each override that drops out.
 struct StatAcc {
-  f2 num2, pn, qn, pd;
-  int n_low;   // pixels on the low-variance branch: den_val = 1 each, counted with scalar popcounts (wave-uniform)
+  f2 num2, den2, pn, qn, pd;
 };
 __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2, const f2 xx, const f2 yy, const f2 xy,
                                           const bool v0, const bool v1, const float gain_limit) {
@@ -153,7 +110,7 @@ __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2
   f2 s2 = yy - mu2 * mu2;
   const f2 s12 = xy - mu1 * mu2;
   s2 = f2{fmaxf(s2.x, 0.0f), fmaxf(s2.y, 0.0f)};
-  // ONE compare per pixel: "low" = sigma1_sq < sigma_nsq (a NaN cannot occur: every input is a finite filter output); the
+  // one compare per pixel ("low" = sigma1_sq < sigma_nsq; every input is a finite filter output, so no NaN case); the
   // branch masks are lane masks in SGPRs, combined with the validity masks by scalar instructions
   const bool lt0 = s1.x < sigma_nsq, lt1 = s1.y < sigma_nsq;
   const bool hx = v0 && !lt0, hy = v1 && !lt1;
@@ -173,9 +130,9 @@ __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2
   s.pn *= narg;
   s.qn *= svn;
   s.pd *= darg;
-  s.num2 += f2{lx ? low.x : 0.0f, ly ? low.y : 0.0f};
-  // den_val = 1 per low pixel: the wave's count of them is a popcount of the lane mask -- scalar unit, no VALU work
-  s.n_low += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lx)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(ly));
+  const f2 wl = f2{lx ? 1.0f : 0.0f, ly ? 1.0f : 0.0f};
+  s.num2 = __builtin_elementwise_fma(wl, low, s.num2);
+  s.den2 += wl;
 }
 
 // PQA_MARCH_LDS_TABLES: the tap fragments of the next scale's input (used once per block each) stay in LDS and are read
@@ -259,13 +216,15 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   // A block whose 16 rows lie inside the image needs no per-lane row arithmetic at all: the lane part of the address
   // (m * pitch + first column) is fixed for the whole march and the block's first row goes into the load's SCALAR offset.
   const unsigned lane_off_r = (unsigned)m * a.pitch_r + (unsigned)(xin * ES), lane_off_d = (unsigned)m * a.pitch_d + (unsigned)(xin * ES);
-  // R / D: the lane's 8 samples, packed as they lie in memory (8 bit: dwords 0, 1; 10 bit: dwords 0..3)
-  const auto load8 = [&](const rsrc_t rs, const unsigned voff, const unsigned soff) -> u4v {
-    if (W16) return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
-    const u2v v = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
-    return u4v{v[0], v[1], 0u, 0u};
+  // R / D: the lane's 8 samples, packed as they lie in memory (8 bit: two dwords; 10 bit: four).  The type is exactly as
+  // wide as the data: these registers are live across the whole block (they are the prefetch), and two spare dwords per
+  // plane were enough to push the 8-bit kernel into spilling its load offsets -- whose reloads then serialised the prefetch.
+  using Raw = std::conditional_t<W16, u4v, u2v>;
+  const auto load8 = [&](const rsrc_t rs, const unsigned voff, const unsigned soff) -> Raw {
+    if constexpr (W16) return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    else return __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
   };
-  const auto load_block = [&](int rb, u4v& R, u4v& D) {
+  const auto load_block = [&](int rb, Raw& R, Raw& D) {
     const int y_first = ys - 8 + 16 * rb;                                 // wave-uniform
     const bool rows_in = y_first >= 0 && y_first + 16 <= a.h;
     if (colfast && rows_in) {
@@ -290,18 +249,18 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
           d[j] = __builtin_amdgcn_raw_buffer_load_b8(rsrc_d, my * a.pitch_d + mx, 0, 0) & 0xffu;
         }
       }
-      if (W16) {
+      if constexpr (W16) {
         R = u4v{r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16)};
         D = u4v{d[0] | (d[1] << 16), d[2] | (d[3] << 16), d[4] | (d[5] << 16), d[6] | (d[7] << 16)};
       } else {
-        R = u4v{r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24), 0u, 0u};
-        D = u4v{d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24), d[4] | (d[5] << 8) | (d[6] << 16) | (d[7] << 24), 0u, 0u};
+        R = u2v{r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24)};
+        D = u2v{d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24), d[4] | (d[5] << 8) | (d[6] << 16) | (d[7] << 24)};
       }
     }
   };
 
   // ---- pass 1 + split: one 16 x 32 input block -> this lane's pieces -----------------------------------------------
-  const auto pass1 = [&](const u4v R, const u4v D, Pieces& P, auto half) {
+  const auto pass1 = [&](const Raw R, const Raw D, Pieces& P, auto half) {
     constexpr int H = decltype(half)::value;
     TD_REFRESH();
     const f4 z = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -311,7 +270,7 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
     unsigned ru[4], du[4], r16[4], d16[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      if (W16) {
+      if constexpr (W16) {
         ru[v] = R[v];
         du[v] = D[v];
       } else {
@@ -338,39 +297,42 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
     }
 #pragma unroll
     for (int s = 2; s < 5; ++s) {   // r'^2, d'^2, r'd': exact integer products, split into two digits
-      unsigned lo_[4], hi_[4];
-      if (!W16) {   // 16-bit products, digits base 256
+      // The digits of one plane are extracted right before the MFMAs that consume them -- low digit, its two MFMAs, high
+      // digit, its three: the extraction of the next operand then issues under the matrix instructions of the previous one
+      // (forming all eight registers first and then five dependent MFMAs back to back cost the 8-bit kernel 10 %).
+      unsigned q[4], p0[4], p1[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const s2v x = __builtin_bit_cast(s2v, s == 3 ? d16[v] : r16[v]);
-          const s2v y = __builtin_bit_cast(s2v, s == 2 ? r16[v] : d16[v]);
-          // the cross term is signed: + 64 * 256 makes both digits unsigned (one v_pk_mad_u16), the 64 comes off below
-          const unsigned q = __builtin_bit_cast(unsigned, s == 4 ? (s2v)(x * y + s2v{0x4000, 0x4000}) : (s2v)(x * y));
-          lo_[v] = __builtin_amdgcn_perm(0u, q, 0x0c020c00u);   // byte 0 of each 16-bit product
-          hi_[v] = __builtin_amdgcn_perm(0u, q, 0x0c030c01u);   // byte 1
-          if (s == 4) hi_[v] = tiny_minus(hi_[v], 0x8040);      // - 64 * 2^-24
-        }
-      } else {      // |v - 512| <= 512: 32-bit products of the sign-extended halves, digits base 1024; the cross term gets
-                    // 256 * 1024 added so that its high digit (in [0, 512]) is unsigned like the squares'
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const unsigned xs = s == 3 ? d16[v] : r16[v], ys = s == 2 ? r16[v] : d16[v];
+      for (int v = 0; v < 4; ++v) {
+        const unsigned xs = s == 3 ? d16[v] : r16[v], ys = s == 2 ? r16[v] : d16[v];
+        if (!W16) {   // 16-bit products; the cross term is signed: + 64 * 256 makes both digits unsigned (one
+                      // v_pk_mad_u16), the 64 comes off below
+          const s2v x = __builtin_bit_cast(s2v, xs), y = __builtin_bit_cast(s2v, ys);
+          q[v] = __builtin_bit_cast(unsigned, s == 4 ? (s2v)(x * y + s2v{0x4000, 0x4000}) : (s2v)(x * y));
+        } else {      // |v - 512| <= 512: 32-bit products of the sign-extended halves; the cross term gets 256 * 1024 added
+                      // so that its high digit (in [0, 512]) is unsigned like the squares'
           const int x0_ = (int)(short)(xs & 0xffffu), x1_ = (int)xs >> 16;
           const int y0_ = (int)(short)(ys & 0xffffu), y1_ = (int)ys >> 16;
           const int add = s == 4 ? (256 << 10) : 0;
-          const unsigned p0 = (unsigned)(x0_ * y0_ + add), p1 = (unsigned)(x1_ * y1_ + add);
-          lo_[v] = ((p1 << 16) & 0x03ff0000u) | (p0 & 0x3ffu);
-          const unsigned hgh = ((p1 << 6) & 0xffff0000u) | (p0 >> 10);
-          hi_[v] = s == 4 ? tiny_minus(hgh, 0x8100) : hgh;       // - 256 * 2^-24
+          p0[v] = (unsigned)(x0_ * y0_ + add);
+          p1[v] = (unsigned)(x1_ * y1_ + add);
         }
       }
-      {
-        const h8 A = frag4(lo_[0], lo_[1], lo_[2], lo_[3]);
+      unsigned t[4];
+      {  // low digit: byte 0 of each 16-bit product / the low 10 bits of each 32-bit product
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          t[v] = W16 ? (((p1[v] << 16) & 0x03ff0000u) | (p0[v] & 0x3ffu)) : __builtin_amdgcn_perm(0u, q[v], 0x0c020c00u);
+        const h8 A = frag4(t[0], t[1], t[2], t[3]);
         Dh[s] = mma(A, T[W16 ? F_L9 : F_LO], z);
         Dh[s] = mma(A, T[W16 ? F_L9 + 1 : F_LO + 1], Dh[s]);
       }
-      {
-        const h8 A = frag4(hi_[0], hi_[1], hi_[2], hi_[3]);
+      {  // high digit: byte 1 / bits 10.. ; the cross term's offset (64 / 256) comes off in f16, exactly
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          t[v] = W16 ? (((p1[v] << 6) & 0xffff0000u) | (p0[v] >> 10)) : __builtin_amdgcn_perm(0u, q[v], 0x0c030c01u);
+          if (s == 4) t[v] = tiny_minus(t[v], W16 ? 0x8100 : 0x8040);
+        }
+        const h8 A = frag4(t[0], t[1], t[2], t[3]);
         Dh[s] = mma(A, T[F_HI], Dh[s]);
         Dh[s] = mma(A, T[F_HI + 1], Dh[s]);
         Dh[s] = mma(A, T[F_HI + 2], Dh[s]);
@@ -391,7 +353,6 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   };
 
   double dnum = 0.0, dden = 0.0;
-  int n_low_wave = 0;   // wave-uniform (scalar) count of low-branch pixels: each contributes den_val = 1
   // validity of this lane's four output columns (wave-uniform per K group, constant over the march)
   bool vcol[4];
 #pragma unroll
@@ -437,16 +398,15 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
     }
     // statistic on this lane's 4 pixels (row yo + m, columns x0 + 4 kq + i)
     const bool vrow = yo + m < a.h;
-    StatAcc st{f2{0.0f, 0.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, 0};
+    StatAcc st{f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}, f2{1.0f, 1.0f}};
     stat_pair(st, f2{V[0][0], V[0][1]}, f2{V[1][0], V[1][1]}, f2{V[2][0], V[2][1]}, f2{V[3][0], V[3][1]},
               f2{V[4][0], V[4][1]}, vrow && vcol[0], vrow && vcol[1], a.gain_limit);
     stat_pair(st, f2{V[0][2], V[0][3]}, f2{V[1][2], V[1][3]}, f2{V[2][2], V[2][3]}, f2{V[3][2], V[3][3]},
               f2{V[4][2], V[4][3]}, vrow && vcol[2], vrow && vcol[3], a.gain_limit);
     const float num = (st.num2.x + st.num2.y) + ((fast_log2(st.pn.x) - fast_log2(st.qn.x)) + (fast_log2(st.pn.y) - fast_log2(st.qn.y)));
-    const float den = fast_log2(st.pd.x) + fast_log2(st.pd.y);
+    const float den = (st.den2.x + st.den2.y) + (fast_log2(st.pd.x) + fast_log2(st.pd.y));
     dnum += (double)num;
     dden += (double)den;
-    n_low_wave += st.n_low;
   };
 
   // Blocks alternate between the two halves of the operand vectors: the even blocks live in dwords {0, 1}, the odd ones in
@@ -458,22 +418,22 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   for (int i = 0; i < 6; ++i) { P.hi[i] = u4v{0u, 0u, 0u, 0u}; P.lo[i] = u4v{0u, 0u, 0u, 0u}; }
   const std::integral_constant<int, 0> even{};
   const std::integral_constant<int, 1> odd{};
-  u4v Rn, Dn;
+  Raw Rn, Dn;
   load_block(0, Rn, Dn);
   {
-    const u4v Rc = Rn, Dc = Dn;
+    const Raw Rc = Rn, Dc = Dn;
     load_block(1, Rn, Dn);   // n_out >= 1: block 1 always exists
     pass1(Rc, Dc, P, even);
   }
   for (int rb = 1; rb <= n_out; rb += 2) {
     {   // odd block -> upper half; window (lower half older, upper half newer)
-      const u4v Rc = Rn, Dc = Dn;
+      const Raw Rc = Rn, Dc = Dn;
       if (rb < n_out) load_block(rb + 1, Rn, Dn);   // in flight while this block is computed
       pass1(Rc, Dc, P, odd);
       pass2(P, F_V, F_VD, ys + 16 * (rb - 1));
     }
     if (rb + 1 <= n_out) {   // even block -> lower half; window (lower half newer, upper half older)
-      const u4v Rc = Rn, Dc = Dn;
+      const Raw Rc = Rn, Dc = Dn;
       if (rb + 1 < n_out) load_block(rb + 2, Rn, Dn);
       pass1(Rc, Dc, P, even);
       pass2(P, F_W, F_WD, ys + 16 * rb);
@@ -481,34 +441,10 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   }
   dnum = wave_sum(dnum);
   dden = wave_sum(dden);
-  if (lane == 0) { part[0] = dnum; part[1] = dden + (double)n_low_wave; }
+  if (lane == 0) { part[0] = dnum; part[1] = dden; }
 }
 
 // ---- host: the per-lane tap-matrix fragments ------------------------------------------------------------------------
-void gaussian(int n, float* out) {   // N taps, sigma = N / 5, normalised in double, stored as float (vif_filter1d_table)
-  double v[17], sum = 0.0;
-  const double sigma = n / 5.0;
-  for (int k = 0; k < n; ++k) {
-    const double d = k - n / 2;
-    v[k] = exp(-0.5 * d * d / (sigma * sigma));
-    sum += v[k];
-  }
-  for (int k = 0; k < n; ++k) out[k] = (float)(v[k] / sum);
-}
-
-// x -> n f16 pieces (round to nearest each time); returns what is left
-double pieces(double x, int n, uint16_t* out /* stride: one fragment */, size_t stride) {
-  double r = x;
-  for (int p = 0; p < n; ++p) {
-    const _Float16 hh = (_Float16)r;
-    uint16_t bits;
-    memcpy(&bits, &hh, 2);
-    out[(size_t)p * stride] = bits;
-    r -= (double)hh;
-  }
-  return r;
-}
-
 bool build_table(uint16_t* out /* [kMarchFrags][64][8] */) {
   float c17[17], c9[9];
   gaussian(17, c17);
@@ -624,14 +560,14 @@ bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun d
   a.n_cb = (w + 15) / 16;
   a.n_cbg = (a.n_cb + 3) / 4;
   a.row_blocks = (h + 15) / 16;
-  // segment length: long enough that the repeated first block is cheap, short enough that a launch has several waves
-  // per SIMD slot to balance (2 048 wave slots at two waves per SIMD)
+  // segment length: long enough that the repeated first block is cheap, short enough that a launch of a full batch has
+  // several waves per SIMD slot to balance.  A function of the GEOMETRY only: a frame's partial sums -- and so its record --
+  // must not depend on how many frames share the launch.
   int seg = a.row_blocks;
-#ifndef PQA_MARCH_WANT_WAVES
-#define PQA_MARCH_WANT_WAVES (16 * 3072)   /* swept 6 144 / 12 288 / 49 152 / 98 304 on the box: 49 152 best by 1 % */
+#ifndef PQA_MARCH_WAVES_PER_FRAME
+#define PQA_MARCH_WAVES_PER_FRAME 1536   /* x 32 frames = 49 152 waves: swept 6 144 .. 98 304 per launch on the box */
 #endif
-  const long long want_waves = PQA_MARCH_WANT_WAVES;
-  while (seg > kMinSegBlocks && (long long)a.n_cbg * 4 * ((a.row_blocks + seg - 1) / seg) * n_frames < want_waves) seg = (seg + 1) / 2;
+  while (seg > kMinSegBlocks && a.n_cbg * 4 * ((a.row_blocks + seg - 1) / seg) < PQA_MARCH_WAVES_PER_FRAME) seg = (seg + 1) / 2;
   if (seg < kMinSegBlocks) seg = a.row_blocks < kMinSegBlocks ? a.row_blocks : kMinSegBlocks;
   a.seg_blocks = seg;
   a.n_seg = (a.row_blocks + seg - 1) / seg;

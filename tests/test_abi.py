@@ -126,3 +126,25 @@ def test_integration_doc_binding_matches_the_header():
     for decl in re.findall(r"^\s*(?:uint32_t|int32_t|double)\s+([\w\s,]+);", struct, re.M):
         hdr_fields += [f.strip() for f in decl.split(",")]
     assert hdr_fields == [n for n, _ in N.PqaConfig._fields_]
+
+
+def test_march_kernels_fit_three_waves_per_simd_without_scratch(tmp_path):
+    """vif_s0_march_kernel keeps a block's loads in flight while the previous block is computed.  A register spill in it is
+    not just slow: the reload's s_waitcnt vmcnt(0) also waits for the prefetch and serialises the march (round 3 lost 10 %
+    that way to two spare dwords in the prefetch registers).  hipcc cross-compiles here: check the compiler's own figures."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "pqa2_amd", "csrc", "vif_march.hip")
+    out = tmp_path / "march.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"^; Function info:.*?^; Occupancy: (\d+)", text, re.S | re.M)
+    scratch = [int(x) for x in re.findall(r"^; ScratchSize: (\d+)", text, re.M)]
+    vgprs = [int(x) for x in re.findall(r"^; TotalNumVgprs: (\d+)", text, re.M)]
+    assert len(scratch) >= 2 and all(s == 0 for s in scratch), scratch          # the 8-bit and the 10-bit instance
+    assert all(v <= 168 for v in vgprs), vgprs                                   # 512 / 3 waves, 8-register granules
+    assert "Folded Reload" not in text and "Folded Spill" not in text
