@@ -141,6 +141,15 @@ PQA_API int pqa_set_stream(pqa_ctx* ctx, void* hip_stream);
 PQA_API int pqa_submit(pqa_ctx* ctx, int64_t frame_index, const void* const ref_planes[3], const int64_t ref_strides[3],
                const void* const dis_planes[3], const int64_t dis_strides[3]);
 
+/* The same for a frame pair that lies in two FILES as packed planes (rows width * sample-size bytes apart, no padding --
+ * raw .yuv and .y4m payloads): plane p of the reference frame starts at byte ref_plane_offsets[p] of ref_fd, likewise for
+ * the distorted clip.  The library reads (pread) straight into its pinned staging with its packing threads -- one copy out
+ * of the page cache and no page faults, against mapping the file and copying from the mapping.  The descriptors are only
+ * read, never closed, and their file positions are not moved.  A short read (truncated file, bad offset) is PQA_EINVAL.
+ * This is the shape of the reference's inputs: two files (app/vmaf_analyzer.py:411-419, `-i distorted -i reference`). */
+PQA_API int pqa_submit_fd(pqa_ctx* ctx, int64_t frame_index, int ref_fd, const int64_t ref_plane_offsets[3], int dis_fd,
+                          const int64_t dis_plane_offsets[3]);
+
 /* Submit n_frames consecutive frame pairs that are ALREADY in device memory (no copies).  "Already" includes ordering:
  * the context's kernels run on its own stream (or the one given to pqa_set_stream), so whatever produced the frames must be
  * complete -- or on that same stream -- before this call; the same holds for pqa_submit_surfaces and

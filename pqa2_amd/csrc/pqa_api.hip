@@ -15,6 +15,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "ingest.h"
 #include "kernels.h"
 
@@ -51,11 +53,37 @@ enum : uint8_t { kSlotEmpty = 0, kSlotSubmitted = 1, kSlotCollected = 2 };
 // rows of a frame pair are split into ~1 MiB tasks that a few persistent helper threads and the caller drain together.
 struct PackTask {
   uint8_t* dst;
-  const uint8_t* src;
+  const uint8_t* src;      // memory source (fd < 0) ...
   int64_t dst_pitch, src_pitch;
   size_t row_bytes;
   int rows;
+  int fd = -1;             // ... or a file: rows lie src_pitch bytes apart from file_off on (pqa_submit_fd)
+  int64_t file_off = 0;
 };
+
+// one task, by whoever takes it.  Returns false on a short read / I/O error of a file source.
+bool run_pack_task(const PackTask& t) {
+  if (t.fd < 0) {
+    if (t.dst_pitch == t.src_pitch) {
+      memcpy(t.dst, t.src, (size_t)t.dst_pitch * (t.rows - 1) + t.row_bytes);
+    } else {
+      for (int y = 0; y < t.rows; ++y) memcpy(t.dst + (int64_t)y * t.dst_pitch, t.src + (int64_t)y * t.src_pitch, t.row_bytes);
+    }
+    return true;
+  }
+  const auto read_all = [&](uint8_t* dst, size_t len, int64_t off) {
+    while (len > 0) {
+      const ssize_t got = pread(t.fd, dst, len, (off_t)off);
+      if (got <= 0) return false;   // EOF inside a frame or an I/O error
+      dst += got; off += got; len -= (size_t)got;
+    }
+    return true;
+  };
+  if (t.dst_pitch == t.src_pitch) return read_all(t.dst, (size_t)t.dst_pitch * (t.rows - 1) + t.row_bytes, t.file_off);
+  for (int y = 0; y < t.rows; ++y)
+    if (!read_all(t.dst + (int64_t)y * t.dst_pitch, t.row_bytes, t.file_off + (int64_t)y * t.src_pitch)) return false;
+  return true;
+}
 
 class PackPool {
  public:
@@ -70,15 +98,16 @@ class PackPool {
     }
   }
   ~PackPool() { shutdown(); }
-  void run(const PackTask* tasks, int n) {
+  bool run(const PackTask* tasks, int n) {   // false: a file source came up short
     {
       std::lock_guard<std::mutex> g(m_);
-      tasks_ = tasks; n_ = n; next_.store(0); finished_ = 0; ++gen_;
+      tasks_ = tasks; n_ = n; next_.store(0); finished_ = 0; failed_.store(false); ++gen_;
     }
     cv_work_.notify_all();
     drain();
     std::unique_lock<std::mutex> g(m_);
     cv_done_.wait(g, [this] { return finished_ == (int)workers_.size(); });
+    return !failed_.load();
   }
 
  private:
@@ -96,12 +125,7 @@ class PackPool {
     for (;;) {
       const int i = next_.fetch_add(1);
       if (i >= n_) break;
-      const PackTask& t = tasks_[i];
-      if (t.dst_pitch == t.src_pitch) {
-        memcpy(t.dst, t.src, (size_t)t.dst_pitch * (t.rows - 1) + t.row_bytes);
-      } else {
-        for (int y = 0; y < t.rows; ++y) memcpy(t.dst + (int64_t)y * t.dst_pitch, t.src + (int64_t)y * t.src_pitch, t.row_bytes);
-      }
+      if (!run_pack_task(tasks_[i])) failed_.store(true);
     }
   }
   void loop() {
@@ -124,6 +148,7 @@ class PackPool {
   const PackTask* tasks_ = nullptr;
   int n_ = 0, finished_ = 0;
   std::atomic<int> next_{0};
+  std::atomic<bool> failed_{false};
   uint64_t gen_ = 0;
   bool stop_ = false;
 };
@@ -717,6 +742,92 @@ void copy_plane_rows(uint8_t* dst, int64_t dst_pitch, const uint8_t* src, int64_
   for (int y = 0; y < h; ++y) memcpy(dst + (int64_t)y * dst_pitch, src + (int64_t)y * src_pitch, row_bytes);
 }
 
+// One frame pair from memory planes or from files into the pinned staging slot, its upload queued on the copy stream.
+struct PlaneSrc {
+  const uint8_t* ptr;   // memory source (fd < 0): rows `stride` bytes apart
+  int64_t stride;
+  int fd;               // file source: rows `stride` bytes apart from `off`
+  int64_t off;
+};
+
+int submit_one(pqa_ctx* c, int64_t frame_index, const PlaneSrc (&src)[2][3]) {
+  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = PQA_OK;
+  if (c->pending > 0 && frame_index != c->pending_first + c->pending) {
+    rc = flush_pending(c);  // non-consecutive index starts a new run: the pending frames claim their slots first
+    if (rc != PQA_OK) return rc;
+  }
+  // before anything is packed (the caller can collect and retry): against the claimed slots, and against the frames still
+  // pending in this run (consecutive indices: they collide only when the run is as long as the ring)
+  rc = check_slots_free(c, frame_index, 1);
+  if (rc != PQA_OK) return rc;
+  if (c->pending >= c->capacity)
+    return fail(c, PQA_ESTATE, "more pending frames than result_capacity %d", c->capacity);
+  rc = ensure_staging(c);
+  if (rc != PQA_OK) return rc;
+  Half& H = c->half[c->cur_half];
+  if (c->pending == 0) {
+    c->pending_first = frame_index;
+    if (H.copied_pending) {  // pinned half still feeding an earlier upload?
+      HIPCHK(c, hipEventSynchronize(H.copied));
+      H.copied_pending = false;
+    }
+    if (H.computed_pending) {  // device half still read by an earlier batch?
+      HIPCHK(c, hipStreamWaitEvent(c->copy_stream, H.computed, 0));
+      H.computed_pending = false;
+    }
+  }
+  uint8_t* slot = H.pinned + (size_t)c->pending * c->slot_bytes;
+  // Pack into the pinned slot in ~1 MiB tasks (a 2160p 4:2:0 pair is 25 MB: one core's memcpy / pread, not PCIe, would
+  // bound this path), drained by the caller and a few persistent helpers.
+  bool ok = true;
+  try {  // no exception may cross the C ABI: if the task list or the helpers cannot be made, that is PQA_ENOMEM below
+    c->pack_tasks.clear();
+    for (int side = 0; side < 2; ++side)
+      for (int p = 0; p < c->n_planes; ++p) {
+        const PlaneSrc& ps = src[side][p];
+        const size_t row_bytes = (size_t)c->pw[p] * c->esize;
+        int rows_per = (int)((1u << 20) / (row_bytes ? row_bytes : 1));
+        if (rows_per < 1) rows_per = 1;
+        for (int y = 0; y < c->ph[p]; y += rows_per) {
+          const int rows = c->ph[p] - y < rows_per ? c->ph[p] - y : rows_per;
+          PackTask t{slot + c->plane_off[side][p] + (int64_t)y * c->slot_row_pitch[p],
+                     ps.fd < 0 ? ps.ptr + (int64_t)y * ps.stride : nullptr, c->slot_row_pitch[p], ps.stride, row_bytes, rows};
+          t.fd = ps.fd;
+          t.file_off = ps.off + (int64_t)y * ps.stride;
+          c->pack_tasks.push_back(t);
+        }
+      }
+    if (c->slot_bytes >= (4u << 20) && !c->pack_pool_tried) {
+      c->pack_pool_tried = true;
+      // threads packing a frame, the caller included.  Default 8: plain host buffers reach the PCIe ceiling with 4, frames
+      // read from files (pread out of the page cache) or out of a memory-mapped file scale further (2160p through
+      // analyze_videos: 880 frames/s with 4, 1 370 with 8, 1 300 with 12 on a 16-CPU share)
+      const char* e = getenv("PQA_PACK_THREADS");
+      int n = e ? atoi(e) : 8;
+      const int hw = (int)std::thread::hardware_concurrency();
+      if (hw > 0 && n > hw) n = hw;
+      if (n > 1) {
+        try { c->pack_pool.reset(new PackPool(n - 1)); } catch (...) { c->pack_pool.reset(); }   // serial packing then
+      }
+    }
+    if (c->pack_pool && c->slot_bytes >= (4u << 20)) {
+      ok = c->pack_pool->run(c->pack_tasks.data(), (int)c->pack_tasks.size());
+    } else {
+      for (const PackTask& t : c->pack_tasks) ok = run_pack_task(t) && ok;
+    }
+  } catch (...) {
+    return fail(c, PQA_ENOMEM, "out of host memory while staging frame %lld", (long long)frame_index);
+  }
+  if (!ok) return fail(c, PQA_EINVAL, "frame %lld: short read from a file source (truncated file or bad plane offset)", (long long)frame_index);
+  HIPCHK(c, hipMemcpyAsync(H.dev + (size_t)c->pending * c->slot_bytes, slot, c->slot_bytes, hipMemcpyHostToDevice,
+                           c->copy_stream));
+  c->pending += 1;
+  if (c->pending == c->HB) return flush_pending(c);
+  return PQA_OK;
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -1104,94 +1215,31 @@ int pqa_submit(pqa_ctx* c, int64_t frame_index, const void* const ref_planes[3],
   if (!c) return PQA_EINVAL;
   if (!ref_planes || !dis_planes || !ref_strides || !dis_strides || frame_index < 0)
     return fail(c, PQA_EINVAL, "bad argument");
-  if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
-  HIPCHK(c, hipSetDevice(c->device));
-  int rc = PQA_OK;
-  if (c->pending > 0 && frame_index != c->pending_first + c->pending) {
-    rc = flush_pending(c);  // non-consecutive index starts a new run: the pending frames claim their slots first
-    if (rc != PQA_OK) return rc;
-  }
-  // before anything is packed (the caller can collect and retry): against the claimed slots, and against the frames still
-  // pending in this run (consecutive indices: they collide only when the run is as long as the ring)
-  rc = check_slots_free(c, frame_index, 1);
-  if (rc != PQA_OK) return rc;
-  if (c->pending >= c->capacity)
-    return fail(c, PQA_ESTATE, "more pending frames than result_capacity %d", c->capacity);
-  rc = ensure_staging(c);
-  if (rc != PQA_OK) return rc;
-  Half& H = c->half[c->cur_half];
-  if (c->pending == 0) {
-    c->pending_first = frame_index;
-    if (H.copied_pending) {  // pinned half still feeding an earlier upload?
-      HIPCHK(c, hipEventSynchronize(H.copied));
-      H.copied_pending = false;
-    }
-    if (H.computed_pending) {  // device half still read by an earlier batch?
-      HIPCHK(c, hipStreamWaitEvent(c->copy_stream, H.computed, 0));
-      H.computed_pending = false;
-    }
-  }
-  uint8_t* slot = H.pinned + (size_t)c->pending * c->slot_bytes;
+  PlaneSrc src[2][3];
   for (int p = 0; p < c->n_planes; ++p) {
     if (!ref_planes[p] || !dis_planes[p]) return fail(c, PQA_EINVAL, "plane %d pointer is null", p);
     const size_t row_bytes = (size_t)c->pw[p] * c->esize;
     if ((size_t)ref_strides[p] < row_bytes || (size_t)dis_strides[p] < row_bytes)
       return fail(c, PQA_EINVAL, "plane %d stride smaller than a row", p);
+    src[0][p] = PlaneSrc{(const uint8_t*)ref_planes[p], ref_strides[p], -1, 0};
+    src[1][p] = PlaneSrc{(const uint8_t*)dis_planes[p], dis_strides[p], -1, 0};
   }
-  // pack into the pinned slot (a 2160p 4:2:0 pair is 25 MB: one core's memcpy, not PCIe, would bound this path)
-  const auto pack = [&](int side, const void* const planes[3], const int64_t strides[3]) {
-    for (int p = 0; p < c->n_planes; ++p)
-      copy_plane_rows(slot + c->plane_off[side][p], c->slot_row_pitch[p], (const uint8_t*)planes[p], strides[p],
-                      (size_t)c->pw[p] * c->esize, c->ph[p]);
-  };
-  bool pooled = false;
-  if (c->slot_bytes >= (4u << 20)) {
-    try {  // no exception may cross the C ABI: if the helpers cannot start, pack serially
-      if (!c->pack_pool_tried) {
-        c->pack_pool_tried = true;
-        // threads packing a frame, the caller included.  Default 8: frames that come out of a memory-mapped file fault
-        // their pages in as they are copied, and that part scales with threads (2160p through analyze_videos: 880
-        // frames/s with 4, 1 370 with 8, 1 300 with 12 on a 16-CPU share); plain host buffers reach the PCIe ceiling with 4
-        const char* e = getenv("PQA_PACK_THREADS");
-        int n = e ? atoi(e) : 8;
-        const int hw = (int)std::thread::hardware_concurrency();
-        if (hw > 0 && n > hw) n = hw;
-        if (n > 1) c->pack_pool.reset(new PackPool(n - 1));
-      }
-      if (c->pack_pool) {
-        c->pack_tasks.clear();
-        for (int side = 0; side < 2; ++side) {
-          const void* const* planes = side ? dis_planes : ref_planes;
-          const int64_t* strides = side ? dis_strides : ref_strides;
-          for (int p = 0; p < c->n_planes; ++p) {
-            const size_t row_bytes = (size_t)c->pw[p] * c->esize;
-            int rows_per = (int)((1u << 20) / (row_bytes ? row_bytes : 1));
-            if (rows_per < 1) rows_per = 1;
-            for (int y = 0; y < c->ph[p]; y += rows_per) {
-              const int rows = c->ph[p] - y < rows_per ? c->ph[p] - y : rows_per;
-              c->pack_tasks.push_back(PackTask{slot + c->plane_off[side][p] + (int64_t)y * c->slot_row_pitch[p],
-                                               (const uint8_t*)planes[p] + (int64_t)y * strides[p],
-                                               c->slot_row_pitch[p], strides[p], row_bytes, rows});
-            }
-          }
-        }
-        c->pack_pool->run(c->pack_tasks.data(), (int)c->pack_tasks.size());
-        pooled = true;
-      }
-    } catch (...) {
-      c->pack_pool.reset();
-      pooled = false;
-    }
+  return submit_one(c, frame_index, src);
+}
+
+int pqa_submit_fd(pqa_ctx* c, int64_t frame_index, int ref_fd, const int64_t ref_plane_offsets[3], int dis_fd,
+                  const int64_t dis_plane_offsets[3]) {
+  if (!c) return PQA_EINVAL;
+  if (ref_fd < 0 || dis_fd < 0 || !ref_plane_offsets || !dis_plane_offsets || frame_index < 0)
+    return fail(c, PQA_EINVAL, "bad argument");
+  PlaneSrc src[2][3];
+  for (int p = 0; p < c->n_planes; ++p) {
+    if (ref_plane_offsets[p] < 0 || dis_plane_offsets[p] < 0) return fail(c, PQA_EINVAL, "plane %d file offset is negative", p);
+    const int64_t row_bytes = (int64_t)c->pw[p] * c->esize;   // planes lie packed in the file: rows row_bytes apart
+    src[0][p] = PlaneSrc{nullptr, row_bytes, ref_fd, ref_plane_offsets[p]};
+    src[1][p] = PlaneSrc{nullptr, row_bytes, dis_fd, dis_plane_offsets[p]};
   }
-  if (!pooled) {
-    pack(0, ref_planes, ref_strides);
-    pack(1, dis_planes, dis_strides);
-  }
-  HIPCHK(c, hipMemcpyAsync(H.dev + (size_t)c->pending * c->slot_bytes, slot, c->slot_bytes, hipMemcpyHostToDevice,
-                           c->copy_stream));
-  c->pending += 1;
-  if (c->pending == c->HB) return flush_pending(c);
-  return PQA_OK;
+  return submit_one(c, frame_index, src);
 }
 
 int pqa_set_motion_halo(pqa_ctx* c, const void* prev_ref_luma_host, int64_t row_stride) {

@@ -82,6 +82,14 @@ class FeatureEngine:
                 ss[p] = a.strides[0]
         self._check(self.lib.pqa_submit(self._ctx, index, C.byref(rp), C.byref(rs), C.byref(dp), C.byref(ds)))
 
+    def submit_file(self, index: int, ref_fd: int, ref_offsets, dis_fd: int, dis_offsets):
+        """A frame pair lying in two files as packed planes (pqa_submit_fd): *_offsets = byte offset of each plane."""
+        S = C.c_int64 * 3
+        ro, do = S(), S()
+        for p in range(self.n_planes):
+            ro[p], do[p] = int(ref_offsets[p]), int(dis_offsets[p])
+        self._check(self.lib.pqa_submit_fd(self._ctx, index, int(ref_fd), C.byref(ro), int(dis_fd), C.byref(do)))
+
     def set_motion_halo(self, prev_ref_luma: np.ndarray | None):
         if prev_ref_luma is None:
             self._check(self.lib.pqa_set_motion_halo(self._ctx, None, 0))

@@ -59,11 +59,17 @@ def score_files(reference_path: str, distorted_path: str, model: str | None = "v
     try:
         if a > 0:
             eng.set_motion_halo(ref_rd.frame(a - 1)[0])   # one-frame halo in front of this rank's chunk
+        # both clips are files of packed planes (.y4m): the library reads them straight into its pinned staging (pqa_submit_fd:
+        # one copy, no page faults) instead of copying frames out of the readers' mappings
+        by_fd = all(hasattr(r, "fileno") and hasattr(r, "plane_offsets") for r in (ref_rd, dis_rd)) and hasattr(eng, "submit_file")
         for i in range(a, b):
             if cancelled is not None and cancelled():
                 eng.cancel()
                 raise N.PqaCancelled(N.PQA_ECANCELLED, "cancelled")
-            eng.submit(i, ref_rd.frame(i)[:n_planes], dis_rd.frame(i)[:n_planes])
+            if by_fd:
+                eng.submit_file(i, ref_rd.fileno(), ref_rd.plane_offsets(i)[:n_planes], dis_rd.fileno(), dis_rd.plane_offsets(i)[:n_planes])
+            else:
+                eng.submit(i, ref_rd.frame(i)[:n_planes], dis_rd.frame(i)[:n_planes])
             if progress is not None:
                 progress(i - a + 1, b - a)
         local = eng.collect(a, b - a) if b > a else np.zeros((0, N.RECORD_DOUBLES))

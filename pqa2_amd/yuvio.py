@@ -136,6 +136,12 @@ class Y4MReader:
     def close(self):
         """Drops the mapping; removes the file too when it is a temporary decode (_decode_with_ffmpeg)."""
         self._mm = None
+        fd, self._fd = getattr(self, "_fd", None), None
+        if fd is not None:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
         tmp, self._tempfile = getattr(self, "_tempfile", None), None
         if tmp:
             try:
@@ -148,6 +154,22 @@ class Y4MReader:
             self.close()
         except Exception:
             pass
+
+    def fileno(self) -> int:
+        """A read-only descriptor of the file (opened on first use, closed with the reader): with plane_offsets() it lets
+        the library read frames straight into its staging (pqa_submit_fd) instead of copying them out of the mapping."""
+        if getattr(self, "_fd", None) is None:
+            self._fd = os.open(self.path, os.O_RDONLY)
+        return self._fd
+
+    def plane_offsets(self, i: int):
+        """Byte offset of each plane of frame i in the file (planes are packed: rows width * sample-size bytes apart)."""
+        off = self._offsets[i]
+        out = []
+        for (h, w) in self.info.plane_shapes:
+            out.append(off)
+            off += h * w * self.info.bytes_per_sample
+        return out
 
     def frame(self, i: int):
         """Planes [Y, U, V] (or [Y]) of frame i as read-only arrays viewing the mapped file."""
@@ -179,12 +201,35 @@ class RawYUVReader:
         if bit_depth is None:
             mb = re.search(r"(\d{1,2})bit", os.path.basename(path))
             bit_depth = int(mb.group(1)) if mb else 8
+        self.path = path
         self.info = VideoInfo(width, height, bit_depth, 1, 1, False, fps, 1)
         self._mm = np.memmap(path, dtype=np.uint8, mode="r")
         self.info.n_frames = self._mm.shape[0] // self.info.frame_bytes
+        self._fd = None
 
     def __len__(self):
         return self.info.n_frames
+
+    def fileno(self) -> int:
+        if self._fd is None:
+            self._fd = os.open(self.path, os.O_RDONLY)
+        return self._fd
+
+    def plane_offsets(self, i: int):
+        off = i * self.info.frame_bytes
+        out = []
+        for (h, w) in self.info.plane_shapes:
+            out.append(off)
+            off += h * w * self.info.bytes_per_sample
+        return out
+
+    def __del__(self):
+        try:
+            if self._fd is not None:
+                os.close(self._fd)
+                self._fd = None
+        except Exception:
+            pass
 
     def frame(self, i: int):
         info = self.info

@@ -227,3 +227,45 @@ def test_analyzer_child_job_drives_torchrun_like_ffmpeg(tmp_path):
     # a failing child surfaces as an error signal carrying the return code, like a failing ffmpeg
     assert not a._run_child_job(rp, str(tmp_path / "nope.y4m"), "vmaf_v0.6.1", jp, None, None, 8)
     assert "return code" in ev["e"][-1]
+
+
+@pytest.mark.gpu
+def test_frames_read_straight_from_files_match_frames_from_memory(tmp_path):
+    """pqa_submit_fd: the library preads packed planes out of two files into its pinned staging (what analyze_videos now does
+    for .y4m / .yuv inputs).  Same records, bit for bit, as the same frames handed over as memory planes -- at a geometry
+    whose staging rows are padded (odd width: row-by-row reads) and at one where a plane is a single read; a truncated file is
+    PQA_EINVAL, not a crash, and the context stays usable."""
+    import os
+    from pqa2_amd import _native as N
+    from pqa2_amd import synth, yuvio
+    from pqa2_amd.engine import FeatureEngine
+    for w, h, bpc in ((322, 182, 8), (640, 360, 10)):
+        n = 5
+        refs, diss = synth.make_clip(w, h, n, bpc, chroma=True)
+        info = synth.clip_info(w, h, bpc)
+        rp, dp = str(tmp_path / f"r_{w}.y4m"), str(tmp_path / f"d_{w}.y4m")
+        yuvio.write_y4m(rp, refs, info)
+        yuvio.write_y4m(dp, diss, info)
+        rr, dr = yuvio.open_video(rp), yuvio.open_video(dp)
+        with FeatureEngine(w, h, bit_depth=bpc, n_planes=3, features=N.FEAT_ALL, max_batch=2) as eng:
+            for i in range(n):
+                eng.submit(i, refs[i], diss[i])
+            mem = eng.collect(0, n)
+        with FeatureEngine(w, h, bit_depth=bpc, n_planes=3, features=N.FEAT_ALL, max_batch=2) as eng:
+            for i in range(n):
+                eng.submit_file(i, rr.fileno(), rr.plane_offsets(i), dr.fileno(), dr.plane_offsets(i))
+            fil = eng.collect(0, n)
+            assert np.array_equal(mem.view(np.uint64), fil.view(np.uint64))
+            # a file that ends inside the frame
+            short = str(tmp_path / "short.y4m")
+            with open(rp, "rb") as f, open(short, "wb") as g:
+                g.write(f.read(rr.plane_offsets(0)[0] + 1000))
+            fd = os.open(short, os.O_RDONLY)
+            try:
+                with pytest.raises(N.PqaError) as e:
+                    eng.submit_file(n, fd, rr.plane_offsets(0), dr.fileno(), dr.plane_offsets(0))
+                assert e.value.code == N.PQA_EINVAL and "short read" in str(e.value)
+            finally:
+                os.close(fd)
+            eng.submit_file(n, rr.fileno(), rr.plane_offsets(1), dr.fileno(), dr.plane_offsets(1))   # still usable
+            assert eng.collect(n, 1).shape == (1, N.RECORD_DOUBLES)
