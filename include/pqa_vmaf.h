@@ -247,6 +247,11 @@ PQA_API int pqa_profile_enable(pqa_ctx* ctx, int on);
 PQA_API int pqa_profile_read(pqa_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches, uint64_t* frames);
 PQA_API const char* pqa_profile_kernel_name(int kernel_id);
 
+/* Test hook (no device needed): the per-lane tap-matrix fragments of the scale-0 VIF kernel, [fragment][lane 0..63][8 f16 bit
+ * patterns], so that a CPU test can replay both matrix passes in numpy against a direct convolution (tests/test_host.py).
+ * Returns the number of fragments, or -(halfwords needed) when `out` is too small. */
+PQA_API int pqa_debug_vif_march_table(uint16_t* out, int32_t capacity_halfwords);
+
 #ifdef __cplusplus
 }
 #endif

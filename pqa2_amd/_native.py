@@ -27,7 +27,7 @@ EXPORTS = [
     "pqa_submit", "pqa_submit_fd", "pqa_submit_device", "pqa_submit_surfaces", "pqa_set_motion_halo", "pqa_flush", "pqa_collect", "pqa_sync",
     "pqa_cancel", "pqa_reset", "pqa_last_error", "pqa_luma_stats_device", "pqa_luma_stats", "pqa_set_luma_gray",
     "pqa_profile_enable",
-    "pqa_profile_read", "pqa_profile_kernel_name",
+    "pqa_profile_read", "pqa_profile_kernel_name", "pqa_debug_vif_march_table",
 ]
 
 
@@ -128,6 +128,7 @@ def load():
     lib.pqa_last_error.restype = C.c_char_p
     lib.pqa_profile_enable.argtypes = [vp, C.c_int]
     lib.pqa_profile_read.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.pqa_debug_vif_march_table.argtypes = [vp, i32]
     lib.pqa_profile_kernel_name.argtypes = [C.c_int]
     lib.pqa_profile_kernel_name.restype = C.c_char_p
     assert lib.pqa_record_doubles() == RECORD_DOUBLES

@@ -1495,6 +1495,8 @@ int pqa_profile_read(pqa_ctx* c, int kernel_id, double* total_ms, uint64_t* laun
   return PQA_OK;
 }
 
+int pqa_debug_vif_march_table(uint16_t* out, int32_t capacity_halfwords) { return vif_march_table(out, capacity_halfwords); }
+
 const char* pqa_profile_kernel_name(int kernel_id) {
   return (kernel_id >= 0 && kernel_id < PQA_PROF_KERNELS) ? kProfNames[kernel_id] : "";
 }

@@ -498,6 +498,12 @@ constexpr int kMinSegBlocks = 8;   // a segment repeats one block of pass 1: (L 
 
 }  // namespace
 
+int vif_march_table(uint16_t* out, int capacity_halfwords) {
+  const int need = kMarchFrags * 64 * 8;
+  if (!out || capacity_halfwords < need) return -need;
+  return build_table(out) ? kMarchFrags : 0;
+}
+
 int vif_march_partials_max(int w, int h) {
   const int n_cbg = ((w + 15) / 16 + 3) / 4, row_blocks = (h + 15) / 16;
   return n_cbg * 4 * ((row_blocks + kMinSegBlocks - 1) / kMinSegBlocks);

@@ -346,3 +346,82 @@ def test_registered_child_jobs_are_stopped_when_the_process_goes(tmp_path):
     va._LIVE_CHILDREN.add(child)
     va._stop_live_children()
     assert child.poll() is not None and child not in va._LIVE_CHILDREN
+
+
+def _march_table():
+    import ctypes as C
+    from pqa2_amd import _native as N
+    lib = N.load()
+    need = -lib.pqa_debug_vif_march_table(None, 0)
+    buf = np.zeros(need, np.uint16)
+    n = lib.pqa_debug_vif_march_table(buf.ctypes.data, need)
+    assert n == 22, n                                              # 0 would mean: a tap does not split exactly into f16 pieces
+    return buf.view(np.float16).reshape(n, 64, 8).astype(np.float64)   # [fragment][lane][element], exact in f64
+
+
+def _as_B(frag):
+    """A fragment as the B operand of v_mfma_f32_16x16x32_f16: lane l supplies B[k = 8 (l >> 4) + j][n = l & 15]."""
+    B = np.zeros((32, 16))
+    for l in range(64):
+        B[8 * (l >> 4):8 * (l >> 4) + 8, l & 15] = frag[l]
+    return B
+
+
+def _gauss(n):
+    d = np.arange(n) - n // 2
+    v = np.exp(-0.5 * d * d / (n / 5.0) ** 2)
+    return (v / v.sum()).astype(np.float32).astype(np.float64)
+
+
+def test_march_tap_tables_replayed_in_numpy_are_the_separable_gaussian():
+    """csrc/vif_march.hip runs both passes of the 17-tap filter as banded matrices on the matrix cores; the second pass takes
+    its operand straight from the first pass's accumulator registers, which only works because the K order of its tap matrix
+    is DEFINED by that register layout.  Replay the whole dataflow on the CPU with the very table the kernel loads
+    (pqa_debug_vif_march_table) -- operand and accumulator lane layouts of v_mfma_f32_16x16x32_f16 spelled out -- and compare
+    with a direct convolution: both passes, both block orders (F_V / F_W), the pieces that must sum to the f32 taps exactly
+    (pass 1) or to 22 bits (pass 2), and the next scale's 9-tap even-row / even-column planes for ref and dis."""
+    T = _march_table()
+    F_HI, F_LO, F_DR, F_DD, F_V, F_VD, F_W, F_WD, F_L9 = 0, 3, 6, 9, 12, 14, 16, 18, 20
+    c17, c9 = _gauss(17), _gauss(9)
+    rng = np.random.default_rng(5)
+
+    # ---- pass 1: D1[row m][slot n] = sum_k X[m][k] * B[k][n], X = 16 rows x 32 window columns (output column n at window n + 8)
+    X = rng.integers(0, 256, (16, 32)).astype(np.float64)
+    want = np.stack([[np.dot(c17, X[m, n:n + 17]) for n in range(16)] for m in range(16)])
+    lo = sum(_as_B(T[F_LO + p]) for p in range(3))                     # c * 2^11, three exact pieces
+    hi = sum(_as_B(T[F_HI + p]) for p in range(3))                     # c * 2^19
+    l9 = sum(_as_B(T[F_L9 + p]) for p in range(2))                     # c * 2^9, two pieces (22 bits of the tap)
+    assert np.array_equal(X @ lo, want * 2048.0) and np.array_equal(X @ hi, want * 524288.0)
+    assert np.abs(X @ l9 / 512.0 - want).max() < 2e-6 * np.abs(want).max()
+    # next scale's input: slots 0..7 = even columns of the plane filtered through F_DR, 8..15 = of the one through F_DD
+    dr = sum(_as_B(T[F_DR + p]) for p in range(3))
+    dd = sum(_as_B(T[F_DD + p]) for p in range(3))
+    Y = rng.integers(0, 256, (16, 32)).astype(np.float64)
+    got = X @ dr + Y @ dd
+    for e in range(8):
+        assert np.allclose(got[:, e], [np.dot(c9, X[m, 2 * e + 4:2 * e + 13]) * 262144.0 for m in range(16)], rtol=0, atol=1e-6)
+        assert np.allclose(got[:, 8 + e], [np.dot(c9, Y[m, 2 * e + 4:2 * e + 13]) * 262144.0 for m in range(16)], rtol=0, atol=1e-6)
+
+    # ---- pass 2: the accumulator of pass 1 leaves lane l = (n = l & 15, kq = l >> 4) with rows 4 kq + i of column n.  The A
+    # operand of the next MFMA takes from that same lane row m = l & 15 (the COLUMN) and K elements 8 kq + j: j < 4 from the
+    # block in dwords {0, 1} of the operand vector, j >= 4 from the block in dwords {2, 3}.
+    P, Cb = rng.standard_normal((16, 16)) * 50, rng.standard_normal((16, 16)) * 50    # previous / current block [row][col]
+
+    def operand(first, second):                    # -> A[col][k]
+        A = np.zeros((16, 32))
+        for col in range(16):
+            for kq in range(4):
+                A[col, 8 * kq:8 * kq + 4] = first[4 * kq:4 * kq + 4, col]
+                A[col, 8 * kq + 4:8 * kq + 8] = second[4 * kq:4 * kq + 4, col]
+        return A
+    W = np.vstack([P, Cb])                                              # the 32-row window; output row n at window row n + 8
+    want2 = np.stack([[np.dot(c17, W[n:n + 17, col]) for n in range(16)] for col in range(16)]) * 256.0
+    v = _as_B(T[F_V]) + _as_B(T[F_V + 1])                               # older block first
+    w_ = _as_B(T[F_W]) + _as_B(T[F_W + 1])                              # newer block first
+    assert np.abs(operand(P, Cb) @ v - want2).max() < 3e-7 * np.abs(want2).max()      # two f16 pieces: 22 bits of each tap
+    assert np.abs(operand(Cb, P) @ w_ - want2).max() < 3e-7 * np.abs(want2).max()
+    vd = _as_B(T[F_VD]) + _as_B(T[F_VD + 1])
+    wd = _as_B(T[F_WD]) + _as_B(T[F_WD + 1])
+    want9 = np.stack([[np.dot(c9, W[2 * e + 4:2 * e + 13, col]) for e in range(8)] for col in range(16)]) * 256.0
+    for got9 in (operand(P, Cb) @ vd, operand(Cb, P) @ wd):
+        assert np.abs(got9[:, :8] - want9).max() < 3e-7 * np.abs(want9).max() and np.all(got9[:, 8:] == 0.0)
