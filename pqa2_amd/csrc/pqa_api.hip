@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include <cerrno>
 #include <unistd.h>
 
 #include "ingest.h"
@@ -74,6 +75,7 @@ bool run_pack_task(const PackTask& t) {
   const auto read_all = [&](uint8_t* dst, size_t len, int64_t off) {
     while (len > 0) {
       const ssize_t got = pread(t.fd, dst, len, (off_t)off);
+      if (got < 0 && errno == EINTR) continue;
       if (got <= 0) return false;   // EOF inside a frame or an I/O error
       dst += got; off += got; len -= (size_t)got;
     }

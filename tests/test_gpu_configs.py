@@ -526,3 +526,38 @@ def test_worst_known_hd_flip_case_stays_bounded():
         full = np.zeros((2, 24)); full[:, :17] = r
         return M.score_frames(mdl, M.metrics_from_records(full, w, h))["vmaf"]
     assert np.abs(vm(got) - vm(d["exp"])).max() < 0.012
+
+
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_march_kernel_takes_any_base_alignment_and_pitch_bit_for_bit(bpc):
+    """vif_s0_march_kernel loads 8 samples per lane with one 8 / 16-byte load when bases and pitches allow it and sample by
+    sample otherwise (and always for the stripes whose columns are mirrored).  A device-resident clip at base offsets 0..7
+    samples into a padded allocation, with an odd pitch, and at widths that are not multiples of 16 must give the very same
+    records as the packed, aligned clip -- the arithmetic does not depend on how the samples were fetched."""
+    import torch
+    from pqa2_amd import _native as N
+    from pqa2_amd import synth
+    from pqa2_amd.engine import FeatureEngine
+    es = 1 if bpc == 8 else 2
+    tdt, ndt = (torch.uint8, np.uint8) if bpc == 8 else (torch.int16, np.int16)
+    for w, h in ((96, 64), (83, 37), (250, 40)):
+        n = 2
+        refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
+        R0 = np.stack([r[0] for r in refs]).view(ndt)
+        D0 = np.stack([d[0] for d in diss]).view(ndt)
+
+        def run(off, pitch):
+            buf_r = torch.zeros(n * h * pitch + 16, dtype=tdt, device="cuda")
+            buf_d = torch.zeros(n * h * pitch + 16, dtype=tdt, device="cuda")
+            vr = buf_r[off:off + n * h * pitch].view(n, h, pitch)
+            vd = buf_d[off:off + n * h * pitch].view(n, h, pitch)
+            vr[:, :, :w] = torch.from_numpy(R0).cuda()
+            vd[:, :, :w] = torch.from_numpy(D0).cuda()
+            torch.cuda.synchronize()
+            with FeatureEngine(w, h, bit_depth=bpc, features=N.FEAT_VIF | N.FEAT_MOTION) as eng:
+                eng.submit_resident(0, n, [vr.data_ptr()], [vd.data_ptr()], [pitch * es], [pitch * h * es])
+                return eng.collect(0, n)[:, :17]
+        base = run(0, ((w + 15) // 16) * 16)
+        for off, pitch in ((1, w), (3, w + 1), (4, w + 8), (7, ((w + 15) // 16) * 16)):
+            got = run(off, pitch)
+            assert np.array_equal(got.view(np.uint64), base.view(np.uint64)), (w, h, off, pitch)
