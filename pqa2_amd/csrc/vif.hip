@@ -16,6 +16,11 @@
 //   3. statistic on the pair, DPP wave sum, one (num, den) double partial per tile; a fixed-order second
 //      stage (finalize.hip) keeps a frame's record independent of batch size and rank count.
 // HBM traffic: the two input planes once (halo re-reads hit L2) + the half-resolution planes written once.
+//
+// Which kernel runs where (launch_vif_stat at the bottom): scales 1-3 and scale 0 of 12-bit clips: vif_stat_kernel (VALU);
+// scale 0 of 8- and 10-bit clips: vif_s0_march_kernel in vif_march.hip (both filter passes on the f16 matrix cores) -- the
+// kernel below that puts only the vertical pass there, vif_s0_mfma_kernel (round 2), remains as its A/B partner
+// (PQA_VIF_MFMA=2) and as the fallback when the march kernel cannot take the caller's next-scale planes.
 #include <cstring>
 #include <mutex>
 #include <vector>
