@@ -334,9 +334,15 @@ def _other_configs(args):
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf = d.get("roofline", {})
             res[wl] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                       "workload": d["config"]["workload"], "roofline_frac": d.get("roofline", {}).get("frac"),
-                       "pipeline_frac": d.get("roofline", {}).get("pipeline_frac")}
+                       "workload": d["config"]["workload"], "roofline_frac": rf.get("frac"),
+                       "pipeline_frac": rf.get("pipeline_frac"), "kernel": rf.get("kernel"),
+                       # the committed rocprofv3 --pmc figures of that workload's dominant kernel (profiles/kernel_counters.json),
+                       # dropped by the child when the kernel source has changed since they were taken
+                       "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
+                       "valu": {k: rf["valu"][k] for k in ("valu_insts_per_wave", "waves_per_frame", "issue_floor_us_per_frame",
+                                                           "measured_us_per_frame", "frac", "source")} if "valu" in rf else None}
         except Exception as e:  # the headline must not depend on this
             res[wl] = {"error": str(e)[:200]}
     return res
