@@ -231,10 +231,9 @@ def main():
             traffic = int(per_frame * frames_per_launch) if per_frame else None
             if args.fixed_point & 1:
                 kname = f"vif_fixed_kernel<{'u8' if bpc == 8 else 'u16'},17,240,9>"
-            elif bpc == 8:    # the march kernel: both filter passes on the f16 matrix cores (csrc/vif_march.hip)
-                kname = "vif_s0_march_kernel (17-tap horizontal pass exact on f16 MFMA, vertical pass on two-piece f16 splits)"
-            elif bpc <= 10:   # the round-2 kernel, interior launch + edge launch, timed together
-                kname = ("vif_s0_mfma_kernel<u16,false> + <..,true> (interior + edge tile pairs; 17-tap vertical pass on f16 MFMA)")
+            elif bpc <= 10:   # the march kernel: both filter passes on the f16 matrix cores (csrc/vif_march.hip)
+                kname = (f"vif_s0_march_kernel<{'u8' if bpc == 8 else 'u16'}> (17-tap horizontal pass exact on f16 MFMA, vertical pass "
+                         f"on two-piece f16 splits)")
             else:
                 kname = "vif_stat_kernel<u16,17,240,9>"
             out["roofline"] = {"bound": "hbm", "bound_is_measured_limiter": False,
@@ -271,22 +270,18 @@ def main():
             if bpc <= 10 and not args.fixed_point:
                 # matrix-core share of the same launches (v_mfma_f32_16x16x32_f16 = 16384 FLOP each; dense f16 peak
                 # 2.5 PFLOP/s, MI355X_MICROARCH.md)
-                if bpc == 8:
-                    # march kernel: per 16 x 16 block 27 MFMAs in pass 1 (repeated once per segment) + 18 in pass 2
-                    n_cb, rbk = (w + 15) // 16, (h + 15) // 16
-                    n_cbg = (n_cb + 3) // 4
-                    seg = rbk
-                    while seg > 8 and n_cbg * 4 * ((rbk + seg - 1) // seg) < 1536:
-                        seg = (seg + 1) // 2
-                    seg = max(seg, min(rbk, 8))
-                    n_seg = (rbk + seg - 1) // seg
-                    mf = n_cb * (27 * (rbk + n_seg) + 18 * rbk) * 16384.0
-                    note = ("45 MFMAs per 16 x 16 output block (27 exact first-pass + 18 second-pass); a Toeplitz band uses 17 of "
-                            "the 32 K slots, so the USEFUL share of these FLOP is about half")
-                else:
-                    pairs = ((w + 239) // 240) * (((h + 7) // 8) // 2)
-                    mf = pairs * 4 * 108 * 16384.0
-                    note = "108 MFMAs per wave and 16-row tile pair, 4 waves per pair (csrc/vif.hip)"
+                # march kernel: per 16 x 16 block 27 MFMAs in pass 1 (repeated once per segment) + 18 in pass 2; the segment
+                # rule is launch_vif_s0_march's (csrc/vif_march.hip)
+                n_cb, rbk = (w + 15) // 16, (h + 15) // 16
+                n_cbg = (n_cb + 3) // 4
+                seg = rbk
+                while seg > 8 and n_cbg * 4 * ((rbk + seg - 1) // seg) < 1536:
+                    seg = (seg + 1) // 2
+                seg = max(seg, min(rbk, 8))
+                n_seg = (rbk + seg - 1) // seg
+                mf = n_cb * (27 * (rbk + n_seg) + 18 * rbk) * 16384.0
+                note = ("45 MFMAs per 16 x 16 output block (27 exact first-pass + 18 second-pass); a Toeplitz band uses 17 of "
+                        "the 32 K slots, so the USEFUL share of these FLOP is about half")
                 out["roofline"]["mfma"] = {"flop_per_frame": mf, "achieved_tflops": round(mf * frames_per_launch / (avg_ms * 1e-3) / 1e12, 1),
                                            "peak_tflops": 2500.0, "frac": round(mf * frames_per_launch / (avg_ms * 1e-3) / 2.5e15, 4),
                                            "note": note + "; the matrix pipe shares its issue port with the VALU: neither fraction can "

@@ -273,10 +273,11 @@ def test_committed_kernel_counters_match_the_kernel_source():
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = json.load(open(os.path.join(root, "profiles", "kernel_counters.json")))
-    e = d["2160p"]["vif_stat_s0"]
-    assert e["src_hash"] == bench.kernel_source_hash(), "profiles/kernel_counters.json is stale: re-run tools/profile_round.sh"
-    assert e["hbm_bytes_per_frame"] > 2 * 3840 * 2160 and e["valu_wave_insts_per_frame"] > 0
-    assert os.path.exists(os.path.join(root, e["traffic_source"].split(" ")[0]))
+    for wl, b_alg in (("2160p", 2 * 3840 * 2160), ("2160p10", 4 * 3840 * 2160)):   # BASELINE configs 3 and 5
+        e = d[wl]["vif_stat_s0"]
+        assert e["src_hash"] == bench.kernel_source_hash(), f"profiles/kernel_counters.json[{wl}] is stale: re-run tools/profile_round.sh"
+        assert e["hbm_bytes_per_frame"] > b_alg and e["valu_wave_insts_per_frame"] > 0
+        assert os.path.exists(os.path.join(root, e["traffic_source"].split(" ")[0]))
 
 
 _FAKE_FFMPEG = r'''#!/usr/bin/env python3

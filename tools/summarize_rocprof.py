@@ -81,7 +81,7 @@ if pmc:
     # + <true> (pairs on an image edge) [+ the VALU kernel on an odd last tile row]; deeper samples the VALU kernel
     ty = "unsigned short" if a.workload == "2160p10" else "unsigned char"
     parts = [k for k in pmc if k.startswith(f"vif_s0_mfma_kernel<{ty}") or k.startswith(f"vif_stat_kernel<{ty}, 17")
-             or (k.startswith("vif_s0_march_kernel") and ty == "unsigned char")]
+             or k.startswith(f"vif_s0_march_kernel<{ty}")]
     k0 = max(parts, key=lambda k: pmc[k]["hbm_bytes_per_frame_corrected"]) if parts else None
     tj = os.path.join(root, "kernel_counters.json")
     cur = json.load(open(tj)) if os.path.exists(tj) else {}
