@@ -337,10 +337,19 @@ static float dwt_quant_step(int lambda, int theta) {
 
 }  // namespace
 
+float adm_dwt_quant_step(int lambda, int theta) { return dwt_quant_step(lambda, theta); }
+
 hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                             int w, int h, float inv_scale, float gain_limit, MutPlaneRun ll_ref,
-                            MutPlaneRun ll_dis, double* partials) {
+                            MutPlaneRun ll_dis, double* partials, int mode, int* n_partials) {
+  if (n_partials) *n_partials = adm_tiles_x((w + 1) / 2) * adm_tiles_y((h + 1) / 2);
   if (n_frames <= 0) return hipSuccess;
+  if (mode == ADM_AUTO) {
+    hipError_t err = hipSuccess;
+    if (launch_adm_march(stream, scale, elem, ref, dis, n_frames, w, h, inv_scale, gain_limit, ll_ref, ll_dis, partials,
+                         n_partials, &err))
+      return err;
+  }
   AdmArgs a{};
   a.ref = ref.base; a.dis = dis.base;
   a.row_pitch_r = ref.row_pitch; a.frame_pitch_r = ref.frame_pitch;

@@ -79,9 +79,20 @@ inline int adm_tiles_y(int band_h) { return (band_h + kAdmTileH - 1) / kAdmTileH
 // partials: [n_frames][tiles][6] doubles (num h,v,d cube sums; den h,v,d cube sums).
 // ll_ref/ll_dis receive the approximation band (ceil(w/2) x ceil(h/2)) for the next scale
 // (base may be null at the last scale).
+// mode (read once per context from PQA_ADM_MARCH in pqa_create): ADM_AUTO = the march kernel (adm_march.hip: one partial
+// sextet per wave segment), ADM_TILED = the LDS-tiled kernel (adm.hip: one per 60 x 14 tile; A/B partner, and the fallback
+// for planes of 2 GiB and more).  *n_partials (nullable) receives the number of sextets per frame the launch wrote.
+enum : int { ADM_TILED = 0, ADM_AUTO = 1 };
 hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                             int w, int h, float inv_scale, float gain_limit, MutPlaneRun ll_ref,
-                            MutPlaneRun ll_dis, double* partials);
+                            MutPlaneRun ll_dis, double* partials, int mode = ADM_AUTO, int* n_partials = nullptr);
+// The march kernel (adm_march.hip).  adm_march_partials: sextets per frame it writes for a band_w x band_h band (workspace
+// sizing; a function of the geometry only).  launch_adm_march returns false when it cannot take the planes.
+int adm_march_partials(int band_w, int band_h);
+bool launch_adm_march(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h,
+                      float inv_scale, float gain_limit, MutPlaneRun ll_ref, MutPlaneRun ll_dis, double* partials,
+                      int* n_partials, hipError_t* err);
+float adm_dwt_quant_step(int lambda, int theta);   // Watson model step (adm_tools.h dwt_quant_step), theta 1 = h/v, 2 = d
 
 // Fixed-point ADM (integer_adm.c arithmetic, adm_fixed.hip).  Same tiling as launch_adm_scale; the approximation
 // bands handed to the next scale are int32 planes (4-byte elements: pass them on as ELEM_F32-sized runs).

@@ -263,6 +263,7 @@ struct pqa_ctx {
   // profiling
   bool multi_stream = false;
   int vif_s0_mode = VIF_S0_AUTO;   // PQA_VIF_MFMA, read once in pqa_create
+  int adm_mode = ADM_AUTO;         // PQA_ADM_MARCH, read once in pqa_create
   bool trace = false;   // PQA_TRACE=1: synchronise after every launch and name it on stderr (localises a stall)
   bool prof = false;
   uint32_t prof_mask = 0xffffffffu;
@@ -439,6 +440,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     if (p0 && p0_pitch % es) return fail(c, PQA_EINVAL, "halo pitch is not a multiple of the sample size");
   }
   int vif_np[4] = {c->vif_tiles[0], c->vif_tiles[1], c->vif_tiles[2], c->vif_tiles[3]};   // partial pairs written per frame
+  int adm_np[4] = {c->adm_tiles[0], c->adm_tiles[1], c->adm_tiles[2], c->adm_tiles[3]};   // partial sextets written per frame
 
   if ((feat & PQA_FEAT_VIF) && sp_n > 0 && c->vif_fixed) {
     PlaneRun cr = rYs, cd = dYs;
@@ -528,7 +530,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       {
         ProfScope ps(c, 7 + s, sp_n, st_adm);
         HIPCHK(c, launch_adm_scale(st_adm, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
-                                   (float)c->cfg.adm_enhn_gain_limit, lr, ld, c->adm_part[s]));
+                                   (float)c->cfg.adm_enhn_gain_limit, lr, ld, c->adm_part[s], c->adm_mode, &adm_np[s]));
       }
       if (s < 3) {
         Level& L = c->adm_lv[s + 1];
@@ -601,7 +603,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   for (int s = 0; s < 4; ++s) {
     fa.vif_part[s] = c->vif_part[s]; fa.vif_tiles[s] = c->vif_fixed ? c->vif_tiles[s] : vif_np[s];
     fa.vif_fx_part[s] = c->vif_fixed ? c->vif_fx_part[s] : nullptr;
-    fa.adm_part[s] = c->adm_part[s]; fa.adm_tiles[s] = c->adm_tiles[s]; fa.adm_area[s] = c->adm_area[s];
+    fa.adm_part[s] = c->adm_part[s]; fa.adm_tiles[s] = c->adm_fixed ? c->adm_tiles[s] : adm_np[s]; fa.adm_area[s] = c->adm_area[s];
     fa.adm_fx_part[s] = c->adm_fixed ? c->adm_fx_part[s] : nullptr;
     fa.adm_fx_tiles_x[s] = adm_tiles_x(c->adm_fx[s].band_w);
     fa.adm_fx_top[s] = c->adm_fx[s].top; fa.adm_fx_bottom[s] = c->adm_fx[s].bottom;
@@ -921,6 +923,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     c->trace = t && t[0] == '1';
     const char* v = getenv("PQA_VIF_MFMA");   // 0: VALU kernels only; 2: the round-2 scale-0 kernel; default: march kernel
     c->vif_s0_mode = (v && v[0] == '0') ? VIF_S0_VALU : (v && v[0] == '2') ? VIF_S0_SPLIT : VIF_S0_AUTO;
+    const char* am = getenv("PQA_ADM_MARCH");  // 0: the LDS-tiled ADM kernel (A/B partner of the march kernel)
+    c->adm_mode = (am && am[0] == '0') ? ADM_TILED : ADM_AUTO;
   }
   for (int i = 0; i < 2; ++i) {
     CREATE_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
@@ -989,8 +993,10 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     if ((cfg->features & PQA_FEAT_VIF) && c->vif_fixed)
       CREATE_TRY(dev_alloc(c, &c->vif_fx_part[s], (size_t)c->vif_tiles[s] * kVifFxPartials * B));
     c->adm_fx[s] = adm_fixed_scale_params(s, bw, bh);
-    if ((cfg->features & PQA_FEAT_ADM) && !c->adm_fixed)
-      CREATE_TRY(dev_alloc(c, &c->adm_part[s], (size_t)c->adm_tiles[s] * 6 * B));
+    if ((cfg->features & PQA_FEAT_ADM) && !c->adm_fixed) {   // one sextet per tile (adm.hip) or per wave segment (adm_march.hip)
+      const int mp = adm_march_partials(bw, bh);
+      CREATE_TRY(dev_alloc(c, &c->adm_part[s], (size_t)(c->adm_tiles[s] > mp ? c->adm_tiles[s] : mp) * 6 * B));
+    }
     if ((cfg->features & PQA_FEAT_ADM) && c->adm_fixed)
       CREATE_TRY(dev_alloc(c, &c->adm_fx_part[s], (size_t)c->adm_tiles[s] * kAdmFxRows * 6 * B));
   }
