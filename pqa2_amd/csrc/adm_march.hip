@@ -97,6 +97,7 @@ template <> struct RawRow<uint8_t, false> { unsigned r, d; };          // two by
 template <> struct RawRow<uint16_t, false> { unsigned r, d; };         // two halfwords each
 template <> struct RawRow<float, false> { f2 r, d; };
 template <typename T> struct RawRow<T, true> { T r0, r1, d0, d1; };
+template <> struct RawRow<float, true> { f2 c0, c1; };   // f32 samples need no conversion: paired as {ref, dis} on arrival
 
 template <typename T, bool EDGE>
 struct RowLoader {
@@ -110,7 +111,10 @@ struct RowLoader {
     const unsigned gy = (unsigned)mirror1(y, h);
     const unsigned so_r = gy * pitch_r, so_d = gy * pitch_d;
     RawRow<T, EDGE> o;
-    if constexpr (EDGE) {
+    if constexpr (EDGE && sizeof(T) == 4) {
+      o.c0 = f2{buf_load<T>(rsrc_r, v0, so_r), buf_load<T>(rsrc_d, v0, so_d)};
+      o.c1 = f2{buf_load<T>(rsrc_r, v1, so_r), buf_load<T>(rsrc_d, v1, so_d)};
+    } else if constexpr (EDGE) {
       o.r0 = buf_load<T>(rsrc_r, v0, so_r); o.r1 = buf_load<T>(rsrc_r, v1, so_r);
       o.d0 = buf_load<T>(rsrc_d, v0, so_d); o.d1 = buf_load<T>(rsrc_d, v1, so_d);
     } else if constexpr (sizeof(T) == 1) {
@@ -126,7 +130,9 @@ struct RowLoader {
     return o;
   }
   __device__ __forceinline__ Row convert(const RawRow<T, EDGE>& x) const {
-    if constexpr (EDGE) {
+    if constexpr (EDGE && sizeof(T) == 4) {
+      return Row{x.c0, x.c1};
+    } else if constexpr (EDGE) {
       return Row{PixIO<T>::pair(x.r0, x.d0, inv_scale), PixIO<T>::pair(x.r1, x.d1, inv_scale)};
     } else if constexpr (sizeof(T) == 1) {
       return Row{PixIO<T>::pair((uint8_t)(x.r & 0xffu), (uint8_t)(x.d & 0xffu), inv_scale),
@@ -242,12 +248,14 @@ __device__ __forceinline__ void march_full(const AdmMarchArgs& a, const RowLoade
     }
   }
   // ---- march.  One step = row i from the carried rows (c0, c1) and the prefetched ones (converted into n0, n1), then the
-  // row above is finished.  Steps alternate between the two halves of the window and of the pending pair, so nothing is
-  // ever copied; the loads for row i + 1 are in flight while row i is computed.
-  RawRow<T, EDGE> nc = ld.load(2 * r0 + 1), nd = ld.load(2 * r0 + 2);
-  const auto step = [&](const Row& c0, const Row& c1, Row& n0, Row& n1, const Pending& above, Pending& mine, const int i, auto is_own) {
-    n0 = ld.convert(nc); n1 = ld.convert(nd);
-    if (decltype(is_own)::value) { nc = ld.load(2 * i + 3); nd = ld.load(2 * i + 4); }
+  // row above is finished.  Steps alternate between the two halves of the window, of the pending pair and of the prefetch
+  // queue, so nothing is ever copied; the loads for rows i + 1 and i + 2 are in flight while row i is computed (a lone wave
+  // of a deep scale's small launch would otherwise spend a full memory latency per row).
+  RawRow<T, EDGE> qa0 = ld.load(2 * r0 + 1), qa1 = ld.load(2 * r0 + 2), qb0 = ld.load(2 * r0 + 3), qb1 = ld.load(2 * r0 + 4);
+  const auto step = [&](const Row& c0, const Row& c1, Row& n0, Row& n1, const Pending& above, Pending& mine,
+                        RawRow<T, EDGE>& q0, RawRow<T, EDGE>& q1, const int i, auto is_own) {
+    n0 = ld.convert(q0); n1 = ld.convert(q1);
+    if (decltype(is_own)::value) { q0 = ld.load(2 * i + 5); q1 = ld.load(2 * i + 6); }   // row i + 2's new rows
     const float rs = row(c0, c1, n0, n1, i, is_own, mine);
     finish(above, s2, rs);
     s2 = rs_prev + rs;
@@ -255,17 +263,17 @@ __device__ __forceinline__ void march_full(const AdmMarchArgs& a, const RowLoade
   };
   int i = r0;
   for (; i + 1 < r1; i += 2) {
-    step(w2, w3, w0, w1, pa, pb, i, own);
-    step(w0, w1, w2, w3, pb, pa, i + 1, own);
+    step(w2, w3, w0, w1, pa, pb, qa0, qa1, i, own);
+    step(w0, w1, w2, w3, pb, pa, qb0, qb1, i + 1, own);
     if (((i - r0) & 6) == 6) flush();
   }
   if (i < r1) {   // odd row count: one more step, then back to the canonical halves
-    step(w2, w3, w0, w1, pa, pb, i, own);
-    w2 = w0; w3 = w1; pa = pb;
+    step(w2, w3, w0, w1, pa, pb, qa0, qa1, i, own);
+    w2 = w0; w3 = w1; pa = pb; qa0 = qb0; qa1 = qb1;
   }
   // ---- the row below the segment again only provides its sum; below the band's last row that sum is the last row's own
   if (r1 < a.oh) {
-    step(w2, w3, w0, w1, pa, pb, r1, guest);
+    step(w2, w3, w0, w1, pa, pb, qa0, qa1, r1, guest);
   } else {
     finish(pa, s2, rs_prev);
   }
@@ -288,19 +296,23 @@ __device__ __forceinline__ void march_ll(const AdmMarchArgs& a, const RowLoader<
                                          float* __restrict__ ll_r, float* __restrict__ ll_d, const unsigned ll_voff) {
   const rsrc_t ll_rs_r = make_rsrc(ll_r, (unsigned)a.oh * a.ll_pitch_r * 4u);
   const rsrc_t ll_rs_d = make_rsrc(ll_d, (unsigned)a.oh * a.ll_pitch_d * 4u);
-  Row xa, xb, xc, xd;
-  xc = ld.convert(ld.load(2 * r0 - 1)); xd = ld.convert(ld.load(2 * r0));
-  RawRow<T, EDGE> nc = ld.load(2 * r0 + 1), nd = ld.load(2 * r0 + 2);
-  for (int i = r0; i < r1; ++i) {
-    xa = xc; xb = xd;
-    xc = ld.convert(nc); xd = ld.convert(nd);
-    if (i + 1 < r1) { nc = ld.load(2 * i + 3); nd = ld.load(2 * i + 4); }
-    const f2 vl0 = dwt_lo(xa.c0, xb.c0, xc.c0, xd.c0), vl1 = dwt_lo(xa.c1, xb.c1, xc.c1, xd.c1);
+  Row w0, w1, w2, w3;
+  w2 = ld.convert(ld.load(2 * r0 - 1)); w3 = ld.convert(ld.load(2 * r0));
+  RawRow<T, EDGE> qa0 = ld.load(2 * r0 + 1), qa1 = ld.load(2 * r0 + 2), qb0 = ld.load(2 * r0 + 3), qb1 = ld.load(2 * r0 + 4);
+  const auto step = [&](const Row& c0, const Row& c1, Row& n0, Row& n1, RawRow<T, EDGE>& q0, RawRow<T, EDGE>& q1, const int i) {
+    n0 = ld.convert(q0); n1 = ld.convert(q1);
+    q0 = ld.load(2 * i + 5); q1 = ld.load(2 * i + 6);
+    const f2 vl0 = dwt_lo(c0.c0, c1.c0, n0.c0, n1.c0), vl1 = dwt_lo(c0.c1, c1.c1, n0.c1, n1.c1);
     const f2 ba = dwt_lo(from_left(vl1), vl0, vl1, from_right(vl0));
-    const unsigned so_r = (unsigned)i * a.ll_pitch_r * 4u, so_d = (unsigned)i * a.ll_pitch_d * 4u;
-    store_f32(ba.x, ll_rs_r, ll_voff, so_r);
-    store_f32(ba.y, ll_rs_d, ll_voff, so_d);
+    store_f32(ba.x, ll_rs_r, ll_voff, (unsigned)i * a.ll_pitch_r * 4u);
+    store_f32(ba.y, ll_rs_d, ll_voff, (unsigned)i * a.ll_pitch_d * 4u);
+  };
+  int i = r0;
+  for (; i + 1 < r1; i += 2) {
+    step(w2, w3, w0, w1, qa0, qa1, i);
+    step(w0, w1, w2, w3, qb0, qb1, i + 1);
   }
+  if (i < r1) step(w2, w3, w0, w1, qa0, qa1, i);
 }
 
 #ifndef PQA_ADM_MARCH_OCC
@@ -355,22 +367,35 @@ __global__ __launch_bounds__(kBlock, PQA_ADM_MARCH_OCC) void adm_march_kernel(co
   }
 }
 
+// Rows per segment: long enough that the two recomputed rows of a segment inside the window are cheap ((L + 2) / L), short
+// enough that a launch has several rounds of waves per SIMD to balance.  Measured on the box (gpurun_out/r04g_*): 32 rows
+// everywhere beat shorter segments for the approximation-band-only regions (a wave's prologue -- six dependent row loads --
+// weighs more the shorter its march) and shorter segments bought the deep scales 3-8 % of launches that cost 0.5-1.5 us per
+// frame; the knobs stay for the next sweep.  Segments are a function of the band's geometry only (a frame's record must not
+// depend on the batch it shares a launch with).
 #ifndef PQA_ADM_SEG_ROWS
-#define PQA_ADM_SEG_ROWS 32
+#define PQA_ADM_SEG_ROWS 32      /* longest segment */
+#endif
+#ifndef PQA_ADM_SEG_MIN
+#define PQA_ADM_SEG_MIN 32       /* shortest */
+#endif
+#ifndef PQA_ADM_WAVES
+#define PQA_ADM_WAVES 384        /* waves per frame and region the segment length aims at (between the two bounds) */
 #endif
 
 struct Partition {
   int reg_start[4], seg_rows[3], seg_first[4];
 };
-// Segments are a function of the band's geometry only (a frame's record must not depend on the batch it shares a launch with).
-Partition partition_rows(int oh, int top, int bottom) {
+Partition partition_rows(int oh, int top, int bottom, int n_stripes) {
   Partition p{};
   p.reg_start[0] = 0; p.reg_start[1] = top; p.reg_start[2] = bottom; p.reg_start[3] = oh;
   int first = 0;
   for (int r = 0; r < 3; ++r) {
     const int len = p.reg_start[r + 1] - p.reg_start[r];
-    const int n = (len + PQA_ADM_SEG_ROWS - 1) / PQA_ADM_SEG_ROWS;           // 0 for an empty region
-    p.seg_rows[r] = n ? (len + n - 1) / n : 1;
+    int rows = (len * n_stripes + PQA_ADM_WAVES - 1) / PQA_ADM_WAVES;
+    rows = rows < PQA_ADM_SEG_MIN ? PQA_ADM_SEG_MIN : rows > PQA_ADM_SEG_ROWS ? PQA_ADM_SEG_ROWS : rows;
+    const int n = (len + rows - 1) / rows;           // 0 for an empty region
+    p.seg_rows[r] = n ? (len + n - 1) / n : 1;       // evened out
     p.seg_first[r] = first;
     first += n ? (len + p.seg_rows[r] - 1) / p.seg_rows[r] : 0;
   }
@@ -382,8 +407,8 @@ Partition partition_rows(int oh, int top, int bottom) {
 
 int adm_march_partials(int band_w, int band_h) {
   const int top = (int)(band_h * 0.1 - 0.5);
-  const Partition p = partition_rows(band_h, top, band_h - top);
   const int n_stripes = (band_w + kStripe - 1) / kStripe;
+  const Partition p = partition_rows(band_h, top, band_h - top, n_stripes);
   return ((n_stripes + 3) / 4) * 4 * p.seg_first[3];
 }
 
@@ -411,7 +436,7 @@ bool launch_adm_march(hipStream_t stream, int scale, Elem elem, PlaneRun ref, Pl
   a.top = (int)(a.oh * border - 0.5);
   a.right = a.ow - a.left;
   a.bottom = a.oh - a.top;
-  const Partition p = partition_rows(a.oh, a.top, a.bottom);
+  const Partition p = partition_rows(a.oh, a.top, a.bottom, a.n_stripes);
   for (int r = 0; r < 4; ++r) { a.reg_start[r] = p.reg_start[r]; a.seg_first[r] = p.seg_first[r]; }
   for (int r = 0; r < 3; ++r) a.seg_rows[r] = p.seg_rows[r];
   a.inv_scale = inv_scale; a.gain_limit = gain_limit;

@@ -409,7 +409,9 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   // fork: the ADM chain and the motion/PSNR/SSIM kernels are independent of the VIF chain; on their own
   // streams they fill the SIMD time the VALU-bound VIF kernels leave while waiting, and the small deep-scale
   // grids overlap instead of running one after another
-  const bool multi = c->multi_stream;
+  // (with EVERY kernel event-timed -- the breakdown pass of bench.py -- the chains stay on one stream, so that a kernel's
+  // figure is its own and not its share of a crowded device; a subset mask, as in the timed region, changes nothing)
+  const bool multi = c->multi_stream && !(c->prof && c->prof_mask == 0xffffffffu);
   hipStream_t st_adm = multi ? c->aux[0] : st, st_misc = multi ? c->aux[1] : st;
   if (multi) {
     HIPCHK(c, hipEventRecord(c->fork_ev, st));
@@ -917,7 +919,11 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   CREATE_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   {
-    const char* e = getenv("PQA_MULTI_STREAM");  // experiment switch: overlap the VIF / ADM / motion chains
+    // PQA_MULTI_STREAM=1: the ADM chain and the motion / PSNR / SSIM kernels on their own streams beside the VIF chain.
+    // With the ADM march kernel (memory-bound at scales 0 / 1) that is worth +2 ... +4 % at 2160p (profiles/r04h_batch_sweep.txt,
+    // r04j_prio.txt) -- but a kernel's launch then lasts as long as its share of a crowded device allows (VIF scale 0: 1.23 ms
+    // instead of 0.76), so the per-kernel figures stop describing the kernels; stream priorities changed nothing.  Off by default.
+    const char* e = getenv("PQA_MULTI_STREAM");
     c->multi_stream = e && e[0] == '1';
     const char* t = getenv("PQA_TRACE");
     c->trace = t && t[0] == '1';
