@@ -211,9 +211,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if not args.fixed_point else f"f32 + fixed-point extractors (mask {args.fixed_point})"), "data": "synthetic",
-            "dtype_note": "every filter and statistic accumulates in f32; VIF scale 0's vertical pass multiplies exact integer digit "
-                          "planes by exact f16 tap pieces on the matrix cores (products exact in f32, f32 accumulators): no "
-                          "reduced-precision arithmetic anywhere",
+            "dtype_note": "every filter and statistic accumulates in f32.  VIF scale 0 (vif_march.hip) runs both passes on the f16 matrix "
+                          "cores: the HORIZONTAL pass multiplies exact integer digit planes by exact three-piece f16 taps (products "
+                          "exact in f32, f32 accumulators); the vertical pass feeds hi/lo f16 splits of those f32 results (about 22 "
+                          "bits, the lo x lo term dropped) against two-piece taps, f32 accumulation -- an f32-grade evaluation in a "
+                          "different rounding order, 8e-8 from f64 on the scale-0 numerator; fuzz bound of the whole path "
+                          "|dVMAF| <= 0.0031 from 500 k pixels up (profiles/r03n_fuzz_summary.txt)",
             "config": {"workload": f"{args.workload} {w}x{h} {bpc}-bit, {model_name}, {F} frames/GPU"
                                    f"{' + PSNR/SSIM all planes' if side else ''}"
                                    f"{f' [--fixed-point {args.fixed_point}: libvmaf integer arithmetic]' if args.fixed_point else ''}",
@@ -251,27 +254,11 @@ def main():
                                # what actually limits the kernel: FP32 issue, not bytes
                                "measured_limiter": "instruction issue: VALU (4 clk per wave64 instruction) + MFMA (8 issue clk of 16 each) on "
                                                    "one port per SIMD, 80 % busy at 3 waves per SIMD (profiles/*_sq_counters.txt); not HBM: see `valu`, `mfma`"}
-            if cnt.get("valu_insts_per_wave"):
-                # issue floor = VALU instructions per wave x waves / (1024 SIMDs x one wave64 instruction per 4 clocks)
-                clk = cnt.get("shader_clock_ghz", 2.0)
-                wave_insts = cnt.get("valu_wave_insts_per_frame") or cnt["valu_insts_per_wave"] * cnt["waves_per_frame"]
-                floor_us = wave_insts * 4.0 / (1024 * clk * 1e3)
-                meas_us = 1e3 * avg_ms / frames_per_launch
-                out["roofline"]["valu"] = {
-                    "valu_insts_per_wave": cnt["valu_insts_per_wave"], "waves_per_frame": cnt["waves_per_frame"],
-                    "valu_wave_insts_per_frame": int(wave_insts),
-                    "shader_clock_ghz": clk, "issue_floor_us_per_frame": round(floor_us, 2),
-                    "measured_us_per_frame": round(meas_us, 2), "frac": round(floor_us / meas_us, 4),
-                    "peak_note": "1024 SIMDs x 1 wave64 VALU instruction / 4 clk: what every non-FMA instruction (convert, select, "
-                                 "permute) and v_pk_fma_f32 cost; SQ_INSTS_VALU counts the MFMAs too (45 per 16 x 16 block), which "
-                                 "hold the issue port 8 clk of their 16 (MI355X_MICROARCH.md cycle constants): a count-based floor, "
-                                 "not a cycle model",
-                    "source": cnt.get("valu_source")}
+            # matrix-core share of the same launches (v_mfma_f32_16x16x32_f16 = 16384 FLOP each; dense f16 peak 2.5 PFLOP/s,
+            # MI355X_MICROARCH.md).  March kernel: per 16 x 16 block 27 MFMAs in pass 1 (repeated once per segment) + 18 in
+            # pass 2; the segment rule is launch_vif_s0_march's (csrc/vif_march.hip)
+            mfma_wave_insts = 0
             if bpc <= 10 and not args.fixed_point:
-                # matrix-core share of the same launches (v_mfma_f32_16x16x32_f16 = 16384 FLOP each; dense f16 peak
-                # 2.5 PFLOP/s, MI355X_MICROARCH.md)
-                # march kernel: per 16 x 16 block 27 MFMAs in pass 1 (repeated once per segment) + 18 in pass 2; the segment
-                # rule is launch_vif_s0_march's (csrc/vif_march.hip)
                 n_cb, rbk = (w + 15) // 16, (h + 15) // 16
                 n_cbg = (n_cb + 3) // 4
                 seg = rbk
@@ -279,7 +266,27 @@ def main():
                     seg = (seg + 1) // 2
                 seg = max(seg, min(rbk, 8))
                 n_seg = (rbk + seg - 1) // seg
-                mf = n_cb * (27 * (rbk + n_seg) + 18 * rbk) * 16384.0
+                mfma_wave_insts = n_cb * (27 * (rbk + n_seg) + 18 * rbk)
+            if cnt.get("valu_insts_per_wave"):
+                # issue floor = the clocks the VALU / matrix issue port of a SIMD is held per frame: SQ_INSTS_VALU counts the
+                # MFMAs too; an MFMA 16x16x32 holds the port 8 clocks (of the 16 it occupies the matrix pipe), every other
+                # counted instruction is priced at 4 (what v_pk_fma_f32, converts, selects, permutes cost; plain v_fma / v_mul /
+                # v_add issue in 2-3: tools/ubench/valu_ops.hip -- so this is an upper estimate of the port time, by a little)
+                clk = cnt.get("shader_clock_ghz", 2.0)
+                wave_insts = cnt.get("valu_wave_insts_per_frame") or cnt["valu_insts_per_wave"] * cnt["waves_per_frame"]
+                mfma_n = min(mfma_wave_insts, wave_insts)
+                floor_us = ((wave_insts - mfma_n) * 4.0 + mfma_n * 8.0) / (1024 * clk * 1e3)
+                meas_us = 1e3 * avg_ms / frames_per_launch
+                out["roofline"]["valu"] = {
+                    "valu_insts_per_wave": cnt["valu_insts_per_wave"], "waves_per_frame": cnt["waves_per_frame"],
+                    "valu_wave_insts_per_frame": int(wave_insts), "mfma_wave_insts_per_frame": int(mfma_n),
+                    "shader_clock_ghz": clk, "issue_floor_us_per_frame": round(floor_us, 2),
+                    "measured_us_per_frame": round(meas_us, 2), "frac": round(floor_us / meas_us, 4),
+                    "peak_note": "issue-port clocks per frame / (1024 SIMDs x shader clock): MFMAs (counted by SQ_INSTS_VALU) at 8 "
+                                 "clocks each, everything else at 4; a count-based model of the port, not a cycle trace",
+                    "source": cnt.get("valu_source")}
+            if mfma_wave_insts:
+                mf = mfma_wave_insts * 16384.0
                 note = ("45 MFMAs per 16 x 16 output block (27 exact first-pass + 18 second-pass); a Toeplitz band uses 17 of "
                         "the 32 K slots, so the USEFUL share of these FLOP is about half")
                 out["roofline"]["mfma"] = {"flop_per_frame": mf, "achieved_tflops": round(mf * frames_per_launch / (avg_ms * 1e-3) / 1e12, 1),
@@ -463,7 +470,8 @@ def kernel_source_hash() -> str:
     import hashlib
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "pqa2_amd", "csrc")
-    for f in ("vif.hip", "vif_march.hip", "pqa_device.h"):   # the scale-0 kernels live in vif.hip / vif_march.hip
+    # the scale-0 kernels live in vif.hip / vif_march.hip; march_common.h holds the march kernel's splits and MFMA wrappers
+    for f in ("vif.hip", "vif_march.hip", "march_common.h", "pqa_device.h"):
         if os.path.exists(os.path.join(d, f)):
             with open(os.path.join(d, f), "rb") as fh:
                 hsh.update(fh.read())

@@ -100,7 +100,7 @@ typedef struct pqa_config {
  * 2048-step log2 table, integer accumulators; implies the integer border), PQA_FIXED_MOTION = integer_motion.c
  * (Q8 blurred planes, integer SAD), PQA_FIXED_ADM = integer_adm.c (Q15 db2, int16/int32 bands, reciprocal table,
  * shifted cube accumulators; the six cube roots per scale are taken on the host inside pqa_collect).
- * Bit-identical to oracle/vmaf_int_oracle.c; slower than the f32 path (DESIGN.md section 1b has the numbers). */
+ * Bit-identical to oracle/vmaf_int_oracle.c; slower than the f32 path (DESIGN.md section 3 has the numbers). */
 enum { PQA_FIXED_VIF = 1, PQA_FIXED_MOTION = 2, PQA_FIXED_ADM = 4, PQA_FIXED_ALL = 7 };
 enum {
   PQA_VIF_BORDER_FLOAT = 0,   /* vif_tools.c:   index -i -> i,  n-1+i -> n-i    */

@@ -96,11 +96,17 @@ def engine_stats_fn(reader, engine, chunk: int = 64, gray: str = "luma"):
     mode = N.GRAY_BT601_FULL if resolve_gray(gray, reader.info) == "bt601_full" else N.GRAY_LUMA
 
     def fn(indices, threshold):
+        # the gray mode is sticky context state: leave the caller's engine as it was found (a later luma_stats with a
+        # luma-unit threshold would otherwise silently count the mapped 8-bit gray)
+        prev = getattr(engine, "luma_gray", N.GRAY_LUMA)
         engine.set_luma_gray(mode)
-        parts = []
-        for a in range(0, len(indices), chunk):
-            frames = [reader.frame(int(i))[0] for i in indices[a:a + chunk]]
-            parts.append(engine.luma_stats(frames, threshold))
+        try:
+            parts = []
+            for a in range(0, len(indices), chunk):
+                frames = [reader.frame(int(i))[0] for i in indices[a:a + chunk]]
+                parts.append(engine.luma_stats(frames, threshold))
+        finally:
+            engine.set_luma_gray(prev)
         return np.concatenate(parts) if parts else np.zeros((0, 3), np.uint64)
     return fn
 

@@ -38,13 +38,14 @@ inline int vif_tiles_y(int h) { return (h + kVifTileH - 1) / kVifTileH; }
 // the tiled kernels, one per wave segment for the march kernel of scale 0 (vif_march.hip); the finalize stage sums that many.
 // s0_mode: which kernel scale 0 runs (read once per context from PQA_VIF_MFMA in pqa_create: A/B runs and the tests that
 // compare the paths): VIF_S0_AUTO = the march kernel (8- and 10-bit clips; 12-bit clips run the VALU kernel);
-// VIF_S0_SPLIT = the round-2 kernel (vertical pass on the matrix cores, horizontal on the VALU); VIF_S0_VALU = VALU only.
-enum : int { VIF_S0_VALU = 0, VIF_S0_AUTO = 1, VIF_S0_SPLIT = 2 };
+// VIF_S0_VALU = VALU only.
+enum : int { VIF_S0_VALU = 0, VIF_S0_AUTO = 1 };
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                            int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
                            MutPlaneRun next_ref, MutPlaneRun next_dis, int s0_mode = VIF_S0_AUTO, int* n_partials = nullptr);
 // Scale 0 of 8- and 10-bit clips, both filter passes on the f16 matrix cores (vif_march.hip).  vif_march_prepare uploads its tap
-// table once per device (pqa_create does; synchronous, idempotent); launch_vif_s0_march returns false when it cannot take
+// table once per device (pqa_create does; synchronous, idempotent; a device that does not keep f16 denormals -- probed once,
+// the operand encoding leans on them -- gets no table and scale 0 stays on the VALU kernel); launch_vif_s0_march returns false when it cannot take
 // the planes (no table, pitches the stores cannot take) and launch_vif_stat then falls back to the tiled kernels.
 // vif_march_partials_max: upper bound of *n_partials for a w x h frame (workspace sizing).
 hipError_t vif_march_prepare();
@@ -55,12 +56,6 @@ int vif_march_table(uint16_t* out, int capacity_halfwords);
 bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
                          int border101, double* partials, MutPlaneRun next_ref, MutPlaneRun next_dis, int* n_partials,
                          hipError_t* err);
-// Scale 0 of 8-bit clips runs its vertical pass on the f16 matrix cores (vif_s0_mfma_kernel: one workgroup per pair of
-// vertically adjacent tiles; same partials, same next-scale planes).  That kernel reads a small per-device table of
-// tap-matrix fragments: upload it once per device BEFORE the first launch (pqa_create does).  Synchronous, idempotent.
-// Without the table -- or with PQA_VIF_MFMA=0, odd pitches / bases -- launch_vif_stat keeps the VALU kernel.
-hipError_t vif_mfma_prepare();
-
 // Fixed-point VIF (integer_vif.c arithmetic, vif_fixed.hip): same tiling; partials are [n_frames][tiles][8] int64
 // {num_log, den_log, x, x2, n_log, den_non_log, num_non_log, -}; next_ref / next_dis are u16 planes (w/2 x h/2).
 // elem: scale 0 reads the caller's samples (ELEM_U8 at 8 bit, ELEM_U16 above), deeper scales ELEM_U16.

@@ -927,8 +927,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     c->multi_stream = e && e[0] == '1';
     const char* t = getenv("PQA_TRACE");
     c->trace = t && t[0] == '1';
-    const char* v = getenv("PQA_VIF_MFMA");   // 0: VALU kernels only; 2: the round-2 scale-0 kernel; default: march kernel
-    c->vif_s0_mode = (v && v[0] == '0') ? VIF_S0_VALU : (v && v[0] == '2') ? VIF_S0_SPLIT : VIF_S0_AUTO;
+    const char* v = getenv("PQA_VIF_MFMA");   // 0: VALU kernels only (the march kernel's test partner); default: march kernel
+    c->vif_s0_mode = (v && v[0] == '0') ? VIF_S0_VALU : VIF_S0_AUTO;
     const char* am = getenv("PQA_ADM_MARCH");  // 0: the LDS-tiled ADM kernel (A/B partner of the march kernel)
     c->adm_mode = (am && am[0] == '0') ? ADM_TILED : ADM_AUTO;
   }
@@ -956,7 +956,6 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     CREATE_TRY(dev_alloc(c, &c->adm_div_lut, lut.size()));
     CREATE_HIP(hipMemcpy(c->adm_div_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
-  if ((cfg->features & PQA_FEAT_VIF) && !c->vif_fixed && cfg->bit_depth <= 10) CREATE_HIP(vif_mfma_prepare());
   if ((cfg->features & PQA_FEAT_VIF) && !c->vif_fixed && cfg->bit_depth <= 10) CREATE_HIP(vif_march_prepare());
   if (c->vif_fixed) {
     std::vector<uint16_t> lut(32768);

@@ -444,6 +444,23 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   if (lane == 0) { part[0] = dnum; part[1] = dden; }
 }
 
+// The operand encoding leans on f16 denormals surviving v_pk_add_f16 and the MFMA operands.  gfx950 keeps them (measured:
+// tools/ubench/f16_denorm.hip), but it is a property of the device and of the kernel's float mode, so every process checks it
+// once before the kernel is allowed to run: column n of B holds the pattern k = 67 n + 1 (minus 1 via the packed add), A is
+// all ones -> D[.][n] = 32 (k - 1) 2^-24 exactly.  ok[0] counts the lanes that saw that.
+__global__ void f16_tiny_probe_kernel(int* ok) {
+  const int lane = threadIdx.x, n = lane & 15;
+  const unsigned k = ((unsigned)n * 67u + 1u) & 0x3ffu;
+  const unsigned t = tiny_minus(k | (k << 16), 0x8001);   // (k - 1) * 2^-24 in both halves
+  const h8 b = frag4(t, t, t, t);
+  h8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (_Float16)1.0f;
+  const f4 d = mma(a, b, f4{0.0f, 0.0f, 0.0f, 0.0f});
+  const float want = 32.0f * (float)(k - 1u) * 5.9604644775390625e-08f;   // 2^-24
+  if (d[0] == want && d[3] == want) atomicAdd(ok, 1);
+}
+
 // ---- host: the per-lane tap-matrix fragments ------------------------------------------------------------------------
 bool build_table(uint16_t* out /* [kMarchFrags][64][8] */) {
   float c17[17], c9[9];
@@ -523,6 +540,29 @@ hipError_t vif_march_prepare() {
   if ((e = hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) {
     (void)hipFree(d);
     return e;
+  }
+  {  // the probe (see f16_tiny_probe_kernel): without kept denormals scale 0 stays on the VALU kernel, and says so once
+    int* ok = nullptr;
+    int seen = 0;
+    if ((e = hipMalloc((void**)&ok, sizeof(int))) == hipSuccess) {
+      e = hipMemset(ok, 0, sizeof(int));
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(f16_tiny_probe_kernel, dim3(1), dim3(64), 0, 0, ok);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpy(&seen, ok, sizeof(int), hipMemcpyDeviceToHost);
+      (void)hipFree(ok);
+    }
+    if (e != hipSuccess) {
+      (void)hipFree(d);
+      return e;
+    }
+    if (seen != 64) {
+      fprintf(stderr, "pqa_vmaf: device %d does not keep f16 denormals (%d of 64 probe lanes exact): VIF scale 0 runs the "
+                      "VALU kernel instead of the matrix-core kernel\n", dev, seen);
+      (void)hipFree(d);
+      return hipSuccess;
+    }
   }
   g_tab[dev] = (const uint4*)d;   // lives as long as the process (20 KB per device)
   return hipSuccess;

@@ -38,6 +38,7 @@ class FeatureEngine:
         self.width, self.height, self.bit_depth, self.n_planes = width, height, bit_depth, n_planes
         self.dtype = np.uint8 if bit_depth <= 8 else np.dtype("<u2")
         self._ctx = C.c_void_p()
+        self.luma_gray = N.GRAY_LUMA   # mirror of the context's sticky gray mode (pqa_set_luma_gray)
         rc = self.lib.pqa_create(C.byref(cfg), C.byref(self._ctx))
         if rc != N.PQA_OK:
             raise N.PqaError(rc, (self.lib.pqa_last_error(None) or b"").decode())
@@ -132,6 +133,7 @@ class FeatureEngine:
         """N.GRAY_LUMA: statistics of the luma samples; N.GRAY_BT601_FULL: of the limited -> full range gray the
         reference's cv2 path sees (8-bit units for every bit depth; thresholds in those units)."""
         self._check(self.lib.pqa_set_luma_gray(self._ctx, int(mode)))
+        self.luma_gray = int(mode)
 
     def luma_stats_resident(self, luma_ptr: int, row_pitch: int, frame_pitch: int, n_frames: int,
                             threshold: int) -> np.ndarray:

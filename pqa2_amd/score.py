@@ -15,22 +15,42 @@ import sys
 import time
 
 
-def _die_with_parent() -> None:
+def _expected_parent() -> int:
+    """The process a worker must not outlive: PQA_PARENT_PID when the launcher exported it (a launcher that starts this
+    module DIRECTLY may do so to close the window between fork and this line; never set it under torchrun, whose agent --
+    not the analyzer -- is the workers' parent), else the parent as it is now.  Read at the very top of main()."""
+    try:
+        return int(os.environ.get("PQA_PARENT_PID", "")) or os.getppid()
+    except ValueError:
+        return os.getppid()
+
+
+def _die_with_parent(expected: int, getppid=os.getppid, kill=os.kill) -> None:
     """A worker must not outlive the job that started it (a rank blocked in the record gather holds its GPU context for
-    ever): ask the kernel for SIGTERM when the parent -- torchrun's agent, or the analyzer for a one-rank job -- goes away.
-    Linux only (prctl PR_SET_PDEATHSIG); elsewhere a no-op."""
+    ever): ask the kernel for SIGTERM when the parent -- torchrun's agent, or whoever started a one-rank job -- goes away.
+    Linux only (prctl PR_SET_PDEATHSIG); elsewhere a no-op.
+
+    The parent may have died BEFORE the request took effect; then this process has already been re-parented and no signal
+    will ever come.  That case is recognised by comparing the parent now with `expected` (the parent at start-up) -- not by
+    `getppid() == 1`: a container's entrypoint or an init-less shell IS pid 1 and perfectly alive, and under a sub-reaper
+    (systemd --user, `docker run --init`, a test harness) an orphan's parent is the reaper, not 1.
+
+    Caveat of PR_SET_PDEATHSIG: it fires when the THREAD that forked this process exits, not the parent process.  A
+    launcher that spawns this module from a short-lived thread (a QThread that returns while the job runs) would end the
+    job early; spawn from a thread that outlives the child.  Under torchrun the workers' parent is the agent's main thread."""
     try:
         import ctypes
         import signal
         libc = ctypes.CDLL(None, use_errno=True)
         libc.prctl(1, int(signal.SIGTERM), 0, 0, 0)   # PR_SET_PDEATHSIG = 1
-        if os.getppid() == 1:                          # the parent was already gone when we asked
-            os.kill(os.getpid(), signal.SIGTERM)
+        if getppid() != expected:                      # re-parented already: the parent went away before we asked
+            kill(os.getpid(), signal.SIGTERM)
     except Exception:
         pass
 
 
 def main(argv=None) -> int:
+    parent = _expected_parent()    # before anything slow: imports, argument parsing
     ap = argparse.ArgumentParser(prog="pqa2_amd.score")
     ap.add_argument("reference")
     ap.add_argument("distorted")
@@ -49,7 +69,7 @@ def main(argv=None) -> int:
 
     from . import report
     from .pipeline import score_files
-    _die_with_parent()
+    _die_with_parent(parent)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

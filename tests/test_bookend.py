@@ -288,9 +288,44 @@ def test_detect_on_the_gpu_engine(tmp_path, bpc, w, h):
         eng.set_luma_gray(N.GRAY_LUMA)
         got = bookend.detect(rd, eng, gray="luma")
         got_full = bookend.detect(rd, eng, gray="bt601_full")
+        # detect() leaves the engine's sticky gray mode as it found it: luma statistics again, bit for bit
+        assert eng.luma_gray == N.GRAY_LUMA
+        assert np.array_equal(eng.luma_stats([rd.frame(i)[0] for i in idx], 200 << (bpc - 8)),
+                              bookend.numpy_stats_fn(rd)(idx, 200 << (bpc - 8)))
     cpu = bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd), gray="luma")
     assert got == cpu                       # same integers in, same floats out
     assert got_full == bookend.detect(rd, stats_fn=bookend.numpy_stats_fn(rd, "bt601_full"), gray="bt601_full")
     _same(got, _reference_style_detect(frames, fps, bpc=bpc))
     _same(got_full, _reference_style_detect(frames, fps, bpc=bpc, gray="bt601_full"))
     assert [(b["start_frame"], b["end_frame"]) for b in got][0][0] == runs[0][0]
+
+
+def test_engine_stats_fn_restores_the_gray_mode_it_found(tmp_path):
+    """The gray mode is sticky context state: the statistics function sets what it needs and puts back what was there,
+    also when the reduction raises (CPU: a stand-in engine that records the calls)."""
+    from pqa2_amd import _native as N
+    path, _ = _clip_with_bookends(tmp_path, 64, 48, 6, 30, [])
+    rd = yuvio.open_video(path)
+
+    class Eng:
+        def __init__(self):
+            self.luma_gray, self.calls, self.fail = N.GRAY_LUMA, [], False
+        def set_luma_gray(self, m):
+            self.luma_gray = m; self.calls.append(m)
+        def luma_stats(self, frames, thr):
+            if self.fail:
+                raise RuntimeError("boom")
+            assert self.luma_gray == N.GRAY_BT601_FULL
+            return np.zeros((len(frames), 3), np.uint64)
+
+    e = Eng()
+    fn = bookend.engine_stats_fn(rd, e, gray="bt601_full")
+    fn([0, 1, 2], 200)
+    assert e.calls == [N.GRAY_BT601_FULL, N.GRAY_LUMA] and e.luma_gray == N.GRAY_LUMA
+    e.set_luma_gray(N.GRAY_BT601_FULL); e.calls.clear()        # a caller who wants the mapped gray keeps it, too
+    fn([0], 200)
+    assert e.luma_gray == N.GRAY_BT601_FULL
+    e.set_luma_gray(N.GRAY_LUMA); e.fail = True
+    with pytest.raises(RuntimeError):
+        fn([0], 200)
+    assert e.luma_gray == N.GRAY_LUMA

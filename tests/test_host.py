@@ -3,6 +3,7 @@ and the VMAFAnalyzer boundary (signals, files, result dict, errors, cancel) -- w
 stand-in engine injected where the HIP engine would be."""
 import json
 import os
+import sys
 import threading
 
 import numpy as np
@@ -426,3 +427,55 @@ def test_march_tap_tables_replayed_in_numpy_are_the_separable_gaussian():
     want9 = np.stack([[np.dot(c9, W[2 * e + 4:2 * e + 13, col]) for e in range(8)] for col in range(16)]) * 256.0
     for got9 in (operand(P, Cb) @ vd, operand(Cb, P) @ wd):
         assert np.abs(got9[:, :8] - want9).max() < 3e-7 * np.abs(want9).max() and np.all(got9[:, 8:] == 0.0)
+
+
+# ---- pqa2_amd.score: a worker must die with its parent, and only then --------------------------------------
+def test_worker_parent_check_does_not_mistake_a_live_pid1_parent_for_a_dead_one():
+    """`getppid() == 1` is not 'the parent is gone': a container entrypoint or an init-less shell IS pid 1.  The check
+    compares the parent now with the parent at start-up instead; a sub-reaper's pid (not 1) counts as re-parented too."""
+    import signal
+    from pqa2_amd import score
+    sent = []
+    kill = lambda pid, sig: sent.append((pid, sig))
+    score._die_with_parent(1, getppid=lambda: 1, kill=kill)            # live parent really is pid 1: nothing happens
+    assert sent == []
+    score._die_with_parent(4321, getppid=lambda: 4321, kill=kill)      # ordinary live parent
+    assert sent == []
+    score._die_with_parent(4321, getppid=lambda: 1, kill=kill)         # orphaned to init before the request took effect
+    score._die_with_parent(4321, getppid=lambda: 777, kill=kill)       # orphaned to a sub-reaper
+    assert sent == [(os.getpid(), signal.SIGTERM)] * 2
+
+
+_REAPER = r'''
+import ctypes, os, subprocess, sys, time
+ctypes.CDLL(None).prctl(36, 1, 0, 0, 0)          # PR_SET_CHILD_SUBREAPER: orphans below come to this process, not to pid 1
+root, orphan, flag = sys.argv[1], sys.argv[2] == "orphan", sys.argv[3]
+# the worker notes its parent, says so (flag file), waits until that parent is gone (orphan case) and only then asks
+worker = ("import os, sys, time; sys.path.insert(0, %r); from pqa2_amd import score; exp = score._expected_parent(); "
+          "open(%r, 'w').close(); t = time.time(); "
+          "[time.sleep(0.02) for _ in iter(lambda: %r and os.getppid() == exp and time.time() - t < 20, False)]; "
+          "score._die_with_parent(exp); time.sleep(0.5); print('survived', flush=True)") % (root, flag, orphan)
+if orphan:   # a middle process starts the worker and exits once the worker has noted it: the worker is re-parented to this reaper
+    mid = subprocess.Popen([sys.executable, "-c", "import os, subprocess, sys, time; subprocess.Popen([sys.executable, '-c', sys.argv[1]])\n"
+                            "while not os.path.exists(sys.argv[2]): time.sleep(0.02)", worker, flag])
+    mid.wait()
+    pid, status = os.wait()                      # the re-parented worker
+    print("worker signal", os.WTERMSIG(status) if os.WIFSIGNALED(status) else 0, flush=True)
+else:        # the worker's parent (this process) stays: it must survive
+    w = subprocess.run([sys.executable, "-c", worker], capture_output=True, text=True)
+    print("worker rc", w.returncode, w.stdout.strip(), flush=True)
+'''
+
+
+@pytest.mark.skipif(not sys.platform.startswith("linux"), reason="prctl")
+def test_worker_dies_when_reparented_to_a_subreaper_and_survives_a_live_parent(tmp_path):
+    """The real thing, no mocks: under a sub-reaper an orphan's parent is the reaper (pid != 1) -- the old `ppid == 1`
+    test missed it; and a worker whose parent is alive must not kill itself."""
+    import signal
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "PQA_PARENT_PID"}
+    r = subprocess.run([sys.executable, "-c", _REAPER, root, "orphan", str(tmp_path / "noted1")], capture_output=True, text=True, timeout=60, env=env)
+    assert f"worker signal {int(signal.SIGTERM)}" in r.stdout, (r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, "-c", _REAPER, root, "alive", str(tmp_path / "noted2")], capture_output=True, text=True, timeout=60, env=env)
+    assert "worker rc 0 survived" in r.stdout, (r.stdout, r.stderr[-500:])
