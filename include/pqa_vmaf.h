@@ -150,6 +150,17 @@ PQA_API int pqa_submit(pqa_ctx* ctx, int64_t frame_index, const void* const ref_
 PQA_API int pqa_submit_fd(pqa_ctx* ctx, int64_t frame_index, int ref_fd, const int64_t ref_plane_offsets[3], int dis_fd,
                           const int64_t dis_plane_offsets[3]);
 
+/* n_frames CONSECUTIVE frame pairs of two such files in one call: frame first_index + k has plane p at byte
+ * ref_plane_offsets[p] + k * ref_frame_stride of ref_fd (a .y4m payload: stride = frame bytes + 6 for "FRAME\n"; raw .yuv:
+ * the frame bytes), likewise for the distorted clip.  Same results as n_frames calls of pqa_submit_fd; inside the call the
+ * packing threads read frame k + 1 while frame k is on its way to the device -- one wake-up of the threads per staging half
+ * (8 frames) instead of one per frame, which is what lets a 2160p clip approach the PCIe rate.  n_frames may be any number
+ * up to result_capacity; a caller that reports progress or polls for cancellation submits in runs of a few frames.
+ * A short read anywhere in a run is PQA_EINVAL and none of the frames of the staging half it occurred in is submitted. */
+PQA_API int pqa_submit_fd_run(pqa_ctx* ctx, int64_t first_index, int32_t n_frames, int ref_fd,
+                              const int64_t ref_plane_offsets[3], int64_t ref_frame_stride, int dis_fd,
+                              const int64_t dis_plane_offsets[3], int64_t dis_frame_stride);
+
 /* Submit n_frames consecutive frame pairs that are ALREADY in device memory (no copies).  "Already" includes ordering:
  * the context's kernels run on its own stream (or the one given to pqa_set_stream), so whatever produced the frames must be
  * complete -- or on that same stream -- before this call; the same holds for pqa_submit_surfaces and

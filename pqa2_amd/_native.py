@@ -24,7 +24,7 @@ GRAY_LUMA, GRAY_BT601_FULL = 0, 1   # pqa_set_luma_gray
 # every symbol include/pqa_vmaf.h declares
 EXPORTS = [
     "pqa_version", "pqa_record_doubles", "pqa_config_init", "pqa_create", "pqa_destroy", "pqa_set_stream",
-    "pqa_submit", "pqa_submit_fd", "pqa_submit_device", "pqa_submit_surfaces", "pqa_set_motion_halo", "pqa_flush", "pqa_collect", "pqa_sync",
+    "pqa_submit", "pqa_submit_fd", "pqa_submit_fd_run", "pqa_submit_device", "pqa_submit_surfaces", "pqa_set_motion_halo", "pqa_flush", "pqa_collect", "pqa_sync",
     "pqa_cancel", "pqa_reset", "pqa_last_error", "pqa_luma_stats_device", "pqa_luma_stats", "pqa_set_luma_gray",
     "pqa_profile_enable",
     "pqa_profile_read", "pqa_profile_kernel_name", "pqa_debug_vif_march_table",
@@ -112,6 +112,7 @@ def load():
     lib.pqa_set_stream.argtypes = [vp, vp]
     lib.pqa_submit.argtypes = [vp, i64, C.POINTER(vp * 3), C.POINTER(i64 * 3), C.POINTER(vp * 3), C.POINTER(i64 * 3)]
     lib.pqa_submit_fd.argtypes = [vp, i64, C.c_int, C.POINTER(i64 * 3), C.c_int, C.POINTER(i64 * 3)]
+    lib.pqa_submit_fd_run.argtypes = [vp, i64, i32, C.c_int, C.POINTER(i64 * 3), i64, C.c_int, C.POINTER(i64 * 3), i64]
     lib.pqa_submit_device.argtypes = [vp, i64, i32, C.POINTER(PqaDeviceClip), C.POINTER(PqaDeviceClip), vp, i64]
     lib.pqa_submit_surfaces.argtypes = [vp, i64, i32, C.POINTER(PqaSurfaceClip), C.POINTER(PqaSurfaceClip),
                                         C.POINTER(PqaSurfaceClip)]

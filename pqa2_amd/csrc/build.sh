@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 OBJS=()
 PIDS=()
 for f in vif vif_march vif_fixed adm adm_march adm_fixed motion motion_fixed psnr_ssim luma_stats finalize ingest pqa_api; do
-  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ kernels.h -nt "$f.o" ] || [ pqa_device.h -nt "$f.o" ] || [ march_common.h -nt "$f.o" ] || [ ingest.h -nt "$f.o" ] || [ ../../include/pqa_vmaf.h -nt "$f.o" ]; then
+  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ kernels.h -nt "$f.o" ] || [ pqa_device.h -nt "$f.o" ] || [ march_common.h -nt "$f.o" ] || [ ingest.h -nt "$f.o" ] || [ host_pack.h -nt "$f.o" ] || [ host_ring.h -nt "$f.o" ] || [ ../../include/pqa_vmaf.h -nt "$f.o" ]; then
     rm -f "$f.o"   # a failed compile must not leave a stale object for the link step
     # adm_march: the SLP vectorizer pairs unrelated scalar multiplies of the decouple chain into v_pk_* ops at the price of
     # register moves and explicit abs (v_and) -- 4-clock instructions where 2-clock ones did (tools/ubench/valu_ops.hip)

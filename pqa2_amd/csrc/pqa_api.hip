@@ -18,10 +18,15 @@
 #include <cerrno>
 #include <unistd.h>
 
+#include "host_pack.h"
+#include "host_ring.h"
 #include "ingest.h"
 #include "kernels.h"
 
 using namespace pqa;
+using pqa::host::PackPool;
+using pqa::host::PackTask;
+using pqa::host::run_pack_task;
 
 namespace {
 
@@ -48,112 +53,6 @@ struct ProfEv {
 
 constexpr int kBatchEvents = 64;  // ring of per-batch completion events
 constexpr int kLumaOutFrames = 2048;  // luma statistics kept on the device between host copies
-enum : uint8_t { kSlotEmpty = 0, kSlotSubmitted = 1, kSlotCollected = 2 };
-
-// pqa_submit packs the caller's planes into pinned staging.  One core's memcpy (~10 GB/s) is far below PCIe, so the
-// rows of a frame pair are split into ~1 MiB tasks that a few persistent helper threads and the caller drain together.
-struct PackTask {
-  uint8_t* dst;
-  const uint8_t* src;      // memory source (fd < 0) ...
-  int64_t dst_pitch, src_pitch;
-  size_t row_bytes;
-  int rows;
-  int fd = -1;             // ... or a file: rows lie src_pitch bytes apart from file_off on (pqa_submit_fd)
-  int64_t file_off = 0;
-};
-
-// one task, by whoever takes it.  Returns false on a short read / I/O error of a file source.
-bool run_pack_task(const PackTask& t) {
-  if (t.fd < 0) {
-    if (t.dst_pitch == t.src_pitch) {
-      memcpy(t.dst, t.src, (size_t)t.dst_pitch * (t.rows - 1) + t.row_bytes);
-    } else {
-      for (int y = 0; y < t.rows; ++y) memcpy(t.dst + (int64_t)y * t.dst_pitch, t.src + (int64_t)y * t.src_pitch, t.row_bytes);
-    }
-    return true;
-  }
-  const auto read_all = [&](uint8_t* dst, size_t len, int64_t off) {
-    while (len > 0) {
-      const ssize_t got = pread(t.fd, dst, len, (off_t)off);
-      if (got < 0 && errno == EINTR) continue;
-      if (got <= 0) return false;   // EOF inside a frame or an I/O error
-      dst += got; off += got; len -= (size_t)got;
-    }
-    return true;
-  };
-  if (t.dst_pitch == t.src_pitch) return read_all(t.dst, (size_t)t.dst_pitch * (t.rows - 1) + t.row_bytes, t.file_off);
-  for (int y = 0; y < t.rows; ++y)
-    if (!read_all(t.dst + (int64_t)y * t.dst_pitch, t.row_bytes, t.file_off + (int64_t)y * t.src_pitch)) return false;
-  return true;
-}
-
-class PackPool {
- public:
-  explicit PackPool(int helpers) {
-    try {
-      for (int i = 0; i < helpers; ++i) workers_.emplace_back([this] { loop(); });
-    } catch (...) {
-      // a std::thread that cannot start (EAGAIN, RLIMIT_NPROC) throws while earlier workers are joinable: unwinding
-      // the vector would call std::terminate.  Stop and join what did start, then let the caller fall back to serial.
-      shutdown();
-      throw;
-    }
-  }
-  ~PackPool() { shutdown(); }
-  bool run(const PackTask* tasks, int n) {   // false: a file source came up short
-    {
-      std::lock_guard<std::mutex> g(m_);
-      tasks_ = tasks; n_ = n; next_.store(0); finished_ = 0; failed_.store(false); ++gen_;
-    }
-    cv_work_.notify_all();
-    drain();
-    std::unique_lock<std::mutex> g(m_);
-    cv_done_.wait(g, [this] { return finished_ == (int)workers_.size(); });
-    return !failed_.load();
-  }
-
- private:
-  void shutdown() noexcept {
-    {
-      std::lock_guard<std::mutex> g(m_);
-      stop_ = true;
-    }
-    cv_work_.notify_all();
-    for (auto& t : workers_)
-      if (t.joinable()) t.join();
-    workers_.clear();
-  }
-  void drain() {
-    for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= n_) break;
-      if (!run_pack_task(tasks_[i])) failed_.store(true);
-    }
-  }
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> g(m_);
-        cv_work_.wait(g, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
-      }
-      drain();
-      std::lock_guard<std::mutex> g(m_);
-      if (++finished_ == (int)workers_.size()) cv_done_.notify_one();
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_work_, cv_done_;
-  const PackTask* tasks_ = nullptr;
-  int n_ = 0, finished_ = 0;
-  std::atomic<int> next_{0};
-  std::atomic<bool> failed_{false};
-  uint64_t gen_ = 0;
-  bool stop_ = false;
-};
 
 // Staging buffers of the host path outlive their context: pinning 2 x 200 MB (2160p 4:2:0, 8 frames) and releasing it again
 // costs ~55 ms per context -- more than scoring a 48-frame 2160p clip -- and the reference's caller makes a fresh analyzer
@@ -244,15 +143,15 @@ struct pqa_ctx {
   size_t plane_off[2][3] = {};
   int64_t slot_row_pitch[3] = {};
   bool staging_ready = false;
+  std::thread pin_thread;            // pins the second staging half while the first one fills (ensure_staging)
+  hipError_t pin_err = hipSuccess;   // its result; read after joining it (staging_half_ready)
   uint8_t* surf_dev = nullptr;   // pqa_submit_surfaces: B slots of unpacked planes (device only, allocated on first use)
   std::unique_ptr<PackPool> pack_pool;
   bool pack_pool_tried = false;
   std::vector<PackTask> pack_tasks;
   // record-ring bookkeeping (host side): which frame a slot holds, whether it was collected, and the batch that
   // writes it.  Lets pqa_collect wait for ITS batch only and makes the PQA_ESTATE promises of the header real.
-  std::vector<int64_t> slot_frame;   // -1: nothing submitted into this slot
-  std::vector<uint8_t> slot_state;   // kSlotEmpty / kSlotSubmitted / kSlotCollected
-  std::vector<uint64_t> slot_seq;    // sequence number of the batch whose finalize writes the slot
+  host::RecordRing ring;             // host_ring.h
   hipEvent_t batch_ev[kBatchEvents] = {};
   uint64_t batch_ev_seq[kBatchEvents] = {};  // sequence number last recorded into each event
   uint64_t batch_seq = 0;            // batches launched so far (the next batch gets batch_seq + 1)
@@ -357,26 +256,16 @@ void prof_drain(pqa_ctx* c) {
 // A slot may be rewritten by the SAME frame index (a re-run) or once its record has been collected; a different
 // frame landing on an uncollected record would lose it silently, so that is a call-sequence error.
 int check_slots_free(pqa_ctx* c, int64_t first, int n) {
-  for (int i = 0; i < n; ++i) {
-    const int64_t f = first + i;
-    const size_t s = (size_t)(f % c->capacity);
-    if (c->slot_state[s] == kSlotSubmitted && c->slot_frame[s] != f)
-      return fail(c, PQA_ESTATE,
-                  "frame %lld would overwrite the uncollected record of frame %lld (result_capacity %d): "
-                  "collect it first or create the context with a larger result_capacity",
-                  (long long)f, (long long)c->slot_frame[s], c->capacity);
-  }
+  int64_t f = 0, holder = 0;
+  if (!c->ring.can_submit(first, n, &f, &holder))
+    return fail(c, PQA_ESTATE,
+                "frame %lld would overwrite the uncollected record of frame %lld (result_capacity %d): "
+                "collect it first or create the context with a larger result_capacity",
+                (long long)f, (long long)holder, c->capacity);
   return PQA_OK;
 }
 
-void claim_slots(pqa_ctx* c, int64_t first, int n, uint64_t seq) {
-  for (int i = 0; i < n; ++i) {
-    const size_t s = (size_t)((first + i) % c->capacity);
-    c->slot_frame[s] = first + i;
-    c->slot_state[s] = kSlotSubmitted;
-    c->slot_seq[s] = seq;
-  }
-}
+void claim_slots(pqa_ctx* c, int64_t first, int n, uint64_t seq) { c->ring.claim(first, n, seq); }
 
 // Wait until batch `seq` (and, the stream being in order, every earlier one) has written its records.
 int wait_batch(pqa_ctx* c, uint64_t seq) {
@@ -703,15 +592,39 @@ int ensure_staging(pqa_ctx* c) {
   }
   for (int i = 0; i < 2; ++i) {
     Half& H = c->half[i];
-    if (!reused) {
-      HIPCHK(c, hipHostMalloc((void**)&H.pinned, half_bytes, hipHostMallocDefault));
-      HIPCHK(c, hipMalloc((void**)&H.dev, half_bytes));
-    }
     HIPCHK(c, hipEventCreateWithFlags(&H.copied, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&H.computed, hipEventDisableTiming));
   }
   HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!reused) {
+    // Pinning costs ~40 us per MiB (a 2160p 4:2:0 half of 8 frame pairs: 8 ms): only the first half is needed before
+    // the first frame can be packed; the second is pinned by a helper thread while the first one fills.
+    HIPCHK(c, hipHostMalloc((void**)&c->half[0].pinned, half_bytes, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc((void**)&c->half[0].dev, half_bytes));
+    const auto pin_second = [c, half_bytes] {
+      hipError_t e = hipSetDevice(c->device);
+      if (e == hipSuccess) e = hipHostMalloc((void**)&c->half[1].pinned, half_bytes, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipMalloc((void**)&c->half[1].dev, half_bytes);
+      c->pin_err = e;
+    };
+    try {
+      c->pin_thread = std::thread(pin_second);
+    } catch (...) {   // no thread to be had: pin it here
+      pin_second();
+    }
+  }
   c->staging_ready = true;
+  return PQA_OK;
+}
+
+// Before half i is touched: the helper thread that pins the second half has to be done with it (joining it also makes
+// its writes to half[1] visible here).
+int staging_half_ready(pqa_ctx* c, int i) {
+  if (i == 0) return PQA_OK;
+  if (c->pin_thread.joinable()) c->pin_thread.join();
+  if (c->pin_err != hipSuccess)
+    return fail(c, c->pin_err == hipErrorOutOfMemory ? PQA_ENOMEM : PQA_EDEVICE, "pinning the second staging half failed: %s",
+                hipGetErrorString(c->pin_err));
   return PQA_OK;
 }
 
@@ -756,82 +669,122 @@ struct PlaneSrc {
   int64_t off;
 };
 
-int submit_one(pqa_ctx* c, int64_t frame_index, const PlaneSrc (&src)[2][3]) {
+// n consecutive frame pairs (frame k's planes lie k * frame_step[side] bytes after src's; memory sources: n == 1) into
+// staging slots and onto the copy stream.  A run is cut into chunks that fit the current staging half; within a chunk the
+// helpers pack frame k + 1 while the caller queues the upload of frame k (PackPool::run_frames): one fork / join per
+// chunk, the link busy from the first completed frame on.
+int submit_run(pqa_ctx* c, int64_t first_index, int n_frames, const PlaneSrc (&src)[2][3], const int64_t (&frame_step)[2]) {
   if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
   HIPCHK(c, hipSetDevice(c->device));
   int rc = PQA_OK;
-  if (c->pending > 0 && frame_index != c->pending_first + c->pending) {
-    rc = flush_pending(c);  // non-consecutive index starts a new run: the pending frames claim their slots first
+  int done = 0;
+  while (done < n_frames) {
+    const int64_t frame_index = first_index + done;
+    if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
+    if (c->pending > 0 && frame_index != c->pending_first + c->pending) {
+      rc = flush_pending(c);  // non-consecutive index starts a new run: the pending frames claim their slots first
+      if (rc != PQA_OK) return rc;
+    }
+    rc = ensure_staging(c);
     if (rc != PQA_OK) return rc;
-  }
-  // before anything is packed (the caller can collect and retry): against the claimed slots, and against the frames still
-  // pending in this run (consecutive indices: they collide only when the run is as long as the ring)
-  rc = check_slots_free(c, frame_index, 1);
-  if (rc != PQA_OK) return rc;
-  if (c->pending >= c->capacity)
-    return fail(c, PQA_ESTATE, "more pending frames than result_capacity %d", c->capacity);
-  rc = ensure_staging(c);
-  if (rc != PQA_OK) return rc;
-  Half& H = c->half[c->cur_half];
-  if (c->pending == 0) {
-    c->pending_first = frame_index;
-    if (H.copied_pending) {  // pinned half still feeding an earlier upload?
-      HIPCHK(c, hipEventSynchronize(H.copied));
-      H.copied_pending = false;
+    int m = n_frames - done;
+    if (m > c->HB - c->pending) m = c->HB - c->pending;
+    if (m > PackPool::kMaxFrames) m = PackPool::kMaxFrames;
+    // before anything is packed (the caller can collect and retry): against the claimed slots, and against the frames still
+    // pending in this run (consecutive indices: they collide only when the run is as long as the ring)
+    rc = check_slots_free(c, frame_index, m);
+    if (rc != PQA_OK) return rc;
+    if (c->pending + m > c->capacity)
+      return fail(c, PQA_ESTATE, "more pending frames than result_capacity %d", c->capacity);
+    rc = staging_half_ready(c, c->cur_half);   // the second half is pinned by a helper thread while the first one fills
+    if (rc != PQA_OK) return rc;
+    Half& H = c->half[c->cur_half];
+    if (c->pending == 0) {
+      c->pending_first = frame_index;
+      if (H.copied_pending) {  // pinned half still feeding an earlier upload?
+        HIPCHK(c, hipEventSynchronize(H.copied));
+        H.copied_pending = false;
+      }
+      if (H.computed_pending) {  // device half still read by an earlier batch?
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, H.computed, 0));
+        H.computed_pending = false;
+      }
     }
-    if (H.computed_pending) {  // device half still read by an earlier batch?
-      HIPCHK(c, hipStreamWaitEvent(c->copy_stream, H.computed, 0));
-      H.computed_pending = false;
-    }
-  }
-  uint8_t* slot = H.pinned + (size_t)c->pending * c->slot_bytes;
-  // Pack into the pinned slot in ~1 MiB tasks (a 2160p 4:2:0 pair is 25 MB: one core's memcpy / pread, not PCIe, would
-  // bound this path), drained by the caller and a few persistent helpers.
-  bool ok = true;
-  try {  // no exception may cross the C ABI: if the task list or the helpers cannot be made, that is PQA_ENOMEM below
-    c->pack_tasks.clear();
-    for (int side = 0; side < 2; ++side)
-      for (int p = 0; p < c->n_planes; ++p) {
-        const PlaneSrc& ps = src[side][p];
-        const size_t row_bytes = (size_t)c->pw[p] * c->esize;
-        int rows_per = (int)((1u << 20) / (row_bytes ? row_bytes : 1));
-        if (rows_per < 1) rows_per = 1;
-        for (int y = 0; y < c->ph[p]; y += rows_per) {
-          const int rows = c->ph[p] - y < rows_per ? c->ph[p] - y : rows_per;
-          PackTask t{slot + c->plane_off[side][p] + (int64_t)y * c->slot_row_pitch[p],
-                     ps.fd < 0 ? ps.ptr + (int64_t)y * ps.stride : nullptr, c->slot_row_pitch[p], ps.stride, row_bytes, rows};
-          t.fd = ps.fd;
-          t.file_off = ps.off + (int64_t)y * ps.stride;
-          c->pack_tasks.push_back(t);
+    const int slot0 = c->pending;
+    // Pack into the pinned slots in ~1 MiB tasks (a 2160p 4:2:0 pair is 25 MB: one core's memcpy / pread, not PCIe, would
+    // bound this path), drained by the caller and a few persistent helpers.
+    bool ok = true;
+    hipError_t copy_err = hipSuccess;
+    const auto upload = [&](int k) {   // frame k of the chunk is complete in its pinned slot: queue its copy
+      const size_t off = (size_t)(slot0 + k) * c->slot_bytes;
+      copy_err = hipMemcpyAsync(H.dev + off, H.pinned + off, c->slot_bytes, hipMemcpyHostToDevice, c->copy_stream);
+      return copy_err == hipSuccess;
+    };
+    try {  // no exception may cross the C ABI: if the task list or the helpers cannot be made, that is PQA_ENOMEM below
+      c->pack_tasks.clear();
+      static const unsigned task_bytes = [] { const char* e = getenv("PQA_PACK_TASK_KB"); const int kb = e ? atoi(e) : 0; return (unsigned)(kb > 0 ? kb : 1024) << 10; }();
+      for (int k = 0; k < m; ++k) {
+        uint8_t* slot = H.pinned + (size_t)(slot0 + k) * c->slot_bytes;
+        for (int side = 0; side < 2; ++side)
+          for (int p = 0; p < c->n_planes; ++p) {
+            const PlaneSrc& ps = src[side][p];
+            const int64_t step = (int64_t)(done + k) * frame_step[side];
+            const size_t row_bytes = (size_t)c->pw[p] * c->esize;
+            int rows_per = (int)(task_bytes / (row_bytes ? row_bytes : 1));
+            if (rows_per < 1) rows_per = 1;
+            for (int y = 0; y < c->ph[p]; y += rows_per) {
+              const int rows = c->ph[p] - y < rows_per ? c->ph[p] - y : rows_per;
+              PackTask t{slot + c->plane_off[side][p] + (int64_t)y * c->slot_row_pitch[p],
+                         ps.fd < 0 ? ps.ptr + step + (int64_t)y * ps.stride : nullptr, c->slot_row_pitch[p], ps.stride, row_bytes, rows};
+              t.fd = ps.fd;
+              t.file_off = ps.off + step + (int64_t)y * ps.stride;
+              t.frame = k;
+              c->pack_tasks.push_back(t);
+            }
+          }
+      }
+      if (c->slot_bytes >= (4u << 20) && !c->pack_pool_tried) {
+        c->pack_pool_tried = true;
+        // threads packing a frame, the caller included.  Default 8: plain host buffers reach the PCIe ceiling with 4, frames
+        // read from files (pread out of the page cache) or out of a memory-mapped file scale further (2160p through
+        // analyze_videos: 880 frames/s with 4, 1 370 with 8; beyond that the box's noise decides, profiles/r04o_pack_threads.txt)
+        const char* e = getenv("PQA_PACK_THREADS");
+        int n = e ? atoi(e) : 8;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && n > hw) n = hw;
+        if (n > 1) {
+          try { c->pack_pool.reset(new PackPool(n - 1)); } catch (...) { c->pack_pool.reset(); }   // serial packing then
         }
       }
-    if (c->slot_bytes >= (4u << 20) && !c->pack_pool_tried) {
-      c->pack_pool_tried = true;
-      // threads packing a frame, the caller included.  Default 8: plain host buffers reach the PCIe ceiling with 4, frames
-      // read from files (pread out of the page cache) or out of a memory-mapped file scale further (2160p through
-      // analyze_videos: 880 frames/s with 4, 1 370 with 8, 1 300 with 12 on a 16-CPU share)
-      const char* e = getenv("PQA_PACK_THREADS");
-      int n = e ? atoi(e) : 8;
-      const int hw = (int)std::thread::hardware_concurrency();
-      if (hw > 0 && n > hw) n = hw;
-      if (n > 1) {
-        try { c->pack_pool.reset(new PackPool(n - 1)); } catch (...) { c->pack_pool.reset(); }   // serial packing then
+      if (c->pack_pool && c->slot_bytes >= (4u << 20)) {
+        ok = c->pack_pool->run_frames(c->pack_tasks.data(), (int)c->pack_tasks.size(), m, upload);
+      } else {
+        int k_done = 0;
+        for (size_t i = 0; i < c->pack_tasks.size() && ok; ++i) {
+          ok = run_pack_task(c->pack_tasks[i]);
+          if (ok && (i + 1 == c->pack_tasks.size() || c->pack_tasks[i + 1].frame != c->pack_tasks[i].frame)) ok = upload(k_done++);
+        }
       }
+    } catch (...) {
+      return fail(c, PQA_ENOMEM, "out of host memory while staging frame %lld", (long long)frame_index);
     }
-    if (c->pack_pool && c->slot_bytes >= (4u << 20)) {
-      ok = c->pack_pool->run(c->pack_tasks.data(), (int)c->pack_tasks.size());
-    } else {
-      for (const PackTask& t : c->pack_tasks) ok = run_pack_task(t) && ok;
+    if (copy_err != hipSuccess) return fail(c, PQA_EDEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(copy_err));
+    if (!ok)   // nothing of this chunk becomes pending: its slots are simply packed again by the next submit
+      return fail(c, PQA_EINVAL, "frame %lld%s: short read from a file source (truncated file or bad plane offset)",
+                  (long long)frame_index, m > 1 ? " (or one of the frames after it in this run)" : "");
+    c->pending += m;
+    done += m;
+    if (c->pending == c->HB) {
+      rc = flush_pending(c);
+      if (rc != PQA_OK) return rc;
     }
-  } catch (...) {
-    return fail(c, PQA_ENOMEM, "out of host memory while staging frame %lld", (long long)frame_index);
   }
-  if (!ok) return fail(c, PQA_EINVAL, "frame %lld: short read from a file source (truncated file or bad plane offset)", (long long)frame_index);
-  HIPCHK(c, hipMemcpyAsync(H.dev + (size_t)c->pending * c->slot_bytes, slot, c->slot_bytes, hipMemcpyHostToDevice,
-                           c->copy_stream));
-  c->pending += 1;
-  if (c->pending == c->HB) return flush_pending(c);
   return PQA_OK;
+}
+
+int submit_one(pqa_ctx* c, int64_t frame_index, const PlaneSrc (&src)[2][3]) {
+  const int64_t no_step[2] = {0, 0};
+  return submit_run(c, frame_index, 1, src, no_step);
 }
 
 }  // namespace
@@ -939,9 +892,7 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   CREATE_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
   for (int i = 0; i < kBatchEvents; ++i) CREATE_HIP(hipEventCreateWithFlags(&c->batch_ev[i], hipEventDisableTiming));
   try {
-    c->slot_frame.assign((size_t)c->capacity, -1);
-    c->slot_state.assign((size_t)c->capacity, kSlotEmpty);
-    c->slot_seq.assign((size_t)c->capacity, 0);
+    c->ring.init(c->capacity);
   } catch (...) {
     fail(c, PQA_ENOMEM, "out of host memory");
     return bail(PQA_ENOMEM);
@@ -1042,6 +993,7 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
 
 void pqa_destroy(pqa_ctx* c) {
   if (!c) return;
+  if (c->pin_thread.joinable()) c->pin_thread.join();
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
@@ -1255,6 +1207,25 @@ int pqa_submit_fd(pqa_ctx* c, int64_t frame_index, int ref_fd, const int64_t ref
   return submit_one(c, frame_index, src);
 }
 
+int pqa_submit_fd_run(pqa_ctx* c, int64_t first_index, int32_t n_frames, int ref_fd, const int64_t ref_plane_offsets[3],
+                      int64_t ref_frame_stride, int dis_fd, const int64_t dis_plane_offsets[3], int64_t dis_frame_stride) {
+  if (!c) return PQA_EINVAL;
+  if (ref_fd < 0 || dis_fd < 0 || !ref_plane_offsets || !dis_plane_offsets || first_index < 0 || n_frames < 0 ||
+      ref_frame_stride < 0 || dis_frame_stride < 0)
+    return fail(c, PQA_EINVAL, "bad argument");
+  if (n_frames > c->capacity)
+    return fail(c, PQA_ESTATE, "%d frames in one call exceed result_capacity %d (records would overwrite each other)", n_frames, c->capacity);
+  PlaneSrc src[2][3];
+  for (int p = 0; p < c->n_planes; ++p) {
+    if (ref_plane_offsets[p] < 0 || dis_plane_offsets[p] < 0) return fail(c, PQA_EINVAL, "plane %d file offset is negative", p);
+    const int64_t row_bytes = (int64_t)c->pw[p] * c->esize;   // planes lie packed in the file: rows row_bytes apart
+    src[0][p] = PlaneSrc{nullptr, row_bytes, ref_fd, ref_plane_offsets[p]};
+    src[1][p] = PlaneSrc{nullptr, row_bytes, dis_fd, dis_plane_offsets[p]};
+  }
+  const int64_t step[2] = {ref_frame_stride, dis_frame_stride};
+  return submit_run(c, first_index, n_frames, src, step);
+}
+
 int pqa_set_motion_halo(pqa_ctx* c, const void* prev_ref_luma_host, int64_t row_stride) {
   if (!c) return PQA_EINVAL;
   if (!(c->cfg.features & PQA_FEAT_MOTION)) return PQA_OK;
@@ -1303,16 +1274,14 @@ int pqa_collect(pqa_ctx* c, int64_t first_index, int32_t count, double* records)
   // every requested frame must be the one its ring slot holds (never submitted / overwritten -> PQA_ESTATE);
   // then wait for the youngest batch among them only -- later batches keep running under the host's work
   uint64_t need = 0;
-  for (int i = 0; i < count; ++i) {
-    const int64_t f = first_index + i;
-    const size_t s = (size_t)(f % c->capacity);
-    if (c->slot_state[s] == kSlotEmpty || c->slot_frame[s] != f) {
-      if (c->slot_state[s] == kSlotEmpty)
-        return fail(c, PQA_ESTATE, "frame %lld was never submitted", (long long)f);
+  {
+    int64_t bad = 0, holder = 0;
+    bool never = false;
+    if (!c->ring.collectable(first_index, count, &need, &bad, &never, &holder)) {
+      if (never) return fail(c, PQA_ESTATE, "frame %lld was never submitted", (long long)bad);
       return fail(c, PQA_ESTATE, "frame %lld was never submitted, or its record was overwritten by frame %lld",
-                  (long long)f, (long long)c->slot_frame[s]);
+                  (long long)bad, (long long)holder);
     }
-    if (c->slot_seq[s] > need) need = c->slot_seq[s];
   }
   rc = wait_batch(c, need);
   if (rc != PQA_OK) return rc;
@@ -1344,7 +1313,7 @@ int pqa_collect(pqa_ctx* c, int64_t first_index, int32_t count, double* records)
     done += n;
     row = 0;
   }
-  for (int i = 0; i < count; ++i) c->slot_state[(size_t)((first_index + i) % c->capacity)] = kSlotCollected;
+  c->ring.mark_collected(first_index, count);
   return PQA_OK;
 }
 
@@ -1472,8 +1441,7 @@ int pqa_reset(pqa_ctx* c) {
   if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
   c->cancelled.store(0);
   c->done_seq = c->batch_seq;
-  std::fill(c->slot_frame.begin(), c->slot_frame.end(), (int64_t)-1);
-  std::fill(c->slot_state.begin(), c->slot_state.end(), (uint8_t)kSlotEmpty);
+  c->ring.reset();
   c->pending = 0;
   c->have_last = false;
   c->halo_armed = false;

@@ -91,6 +91,15 @@ class FeatureEngine:
             ro[p], do[p] = int(ref_offsets[p]), int(dis_offsets[p])
         self._check(self.lib.pqa_submit_fd(self._ctx, index, int(ref_fd), C.byref(ro), int(dis_fd), C.byref(do)))
 
+    def submit_file_run(self, first_index: int, n_frames: int, ref_fd: int, ref_offsets, ref_frame_stride: int,
+                        dis_fd: int, dis_offsets, dis_frame_stride: int):
+        """n_frames consecutive frame pairs of two files (pqa_submit_fd_run): frame first_index + k has plane p at
+        *_offsets[p] + k * *_frame_stride.  The library pipelines reading and upload inside the call."""
+        ro = (C.c_int64 * 3)(*[int(x) for x in list(ref_offsets) + [0] * (3 - len(ref_offsets))])
+        do = (C.c_int64 * 3)(*[int(x) for x in list(dis_offsets) + [0] * (3 - len(dis_offsets))])
+        self._check(self.lib.pqa_submit_fd_run(self._ctx, int(first_index), int(n_frames), int(ref_fd), C.byref(ro),
+                                               int(ref_frame_stride), int(dis_fd), C.byref(do), int(dis_frame_stride)))
+
     def set_motion_halo(self, prev_ref_luma: np.ndarray | None):
         if prev_ref_luma is None:
             self._check(self.lib.pqa_set_motion_halo(self._ctx, None, 0))

@@ -4,6 +4,7 @@ frame pair, gather, apply the model.  Works as a single process (world_size 1) o
 frame-sharded torch.distributed job (one process per GPU)."""
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -62,16 +63,31 @@ def score_files(reference_path: str, distorted_path: str, model: str | None = "v
         # both clips are files of packed planes (.y4m): the library reads them straight into its pinned staging (pqa_submit_fd:
         # one copy, no page faults) instead of copying frames out of the readers' mappings
         by_fd = all(hasattr(r, "fileno") and hasattr(r, "plane_offsets") for r in (ref_rd, dis_rd)) and hasattr(eng, "submit_file")
-        for i in range(a, b):
+        # ... and a run of frames that lie equally spaced in both files goes down in ONE call (pqa_submit_fd_run: reading frame
+        # k + 1 overlaps the upload of frame k inside the library); 8 = a staging half, and the grain of progress / cancel
+        by_run = (by_fd and hasattr(eng, "submit_file_run") and all(hasattr(r, "run_stride") for r in (ref_rd, dis_rd))
+                  and os.environ.get("PQA_FD_RUN", "1") != "0")   # PQA_FD_RUN=0: frame by frame (A/B partner)
+        i = a
+        while i < b:
             if cancelled is not None and cancelled():
                 eng.cancel()
                 raise N.PqaCancelled(N.PQA_ECANCELLED, "cancelled")
-            if by_fd:
+            m = 1
+            if by_run:
+                m = min(8, b - i)
+                rs, ds = ref_rd.run_stride(i, m), dis_rd.run_stride(i, m)
+                if rs is None or ds is None:
+                    m = 1
+            if m > 1:
+                eng.submit_file_run(i, m, ref_rd.fileno(), ref_rd.plane_offsets(i)[:n_planes], rs,
+                                    dis_rd.fileno(), dis_rd.plane_offsets(i)[:n_planes], ds)
+            elif by_fd:
                 eng.submit_file(i, ref_rd.fileno(), ref_rd.plane_offsets(i)[:n_planes], dis_rd.fileno(), dis_rd.plane_offsets(i)[:n_planes])
             else:
                 eng.submit(i, ref_rd.frame(i)[:n_planes], dis_rd.frame(i)[:n_planes])
+            i += m
             if progress is not None:
-                progress(i - a + 1, b - a)
+                progress(i - a, b - a)
         local = eng.collect(a, b - a) if b > a else np.zeros((0, N.RECORD_DOUBLES))
     finally:
         eng.close()

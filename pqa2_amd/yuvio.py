@@ -171,6 +171,14 @@ class Y4MReader:
             off += h * w * self.info.bytes_per_sample
         return out
 
+    def run_stride(self, i: int, n: int):
+        """Byte distance between consecutive frames i .. i + n - 1 when it is constant (it is unless FRAME headers carry
+        parameters of varying length), else None: what pqa_submit_fd_run needs to take the run in one call."""
+        if n <= 1:
+            return 0
+        d = self._offsets[i + 1] - self._offsets[i]
+        return int(d) if all(self._offsets[k + 1] - self._offsets[k] == d for k in range(i, i + n - 1)) else None
+
     def frame(self, i: int):
         """Planes [Y, U, V] (or [Y]) of frame i as read-only arrays viewing the mapped file."""
         info = self.info
@@ -214,6 +222,9 @@ class RawYUVReader:
         if self._fd is None:
             self._fd = os.open(self.path, os.O_RDONLY)
         return self._fd
+
+    def run_stride(self, i: int, n: int):
+        return int(self.info.frame_bytes)
 
     def plane_offsets(self, i: int):
         off = i * self.info.frame_bytes

@@ -269,3 +269,70 @@ def test_frames_read_straight_from_files_match_frames_from_memory(tmp_path):
                 os.close(fd)
             eng.submit_file(n, rr.fileno(), rr.plane_offsets(1), dr.fileno(), dr.plane_offsets(1))   # still usable
             assert eng.collect(n, 1).shape == (1, N.RECORD_DOUBLES)
+
+
+@pytest.mark.gpu
+def test_a_run_of_frames_from_files_in_one_call_matches_frame_by_frame(tmp_path):
+    """pqa_submit_fd_run: n consecutive frame pairs of two files in one call (the library overlaps reading frame k + 1 with
+    the upload of frame k).  Bit-identical to frame-by-frame pqa_submit_fd whatever the run length and however the runs
+    fall on the staging halves (max_batch 2 and 8: halves of 2 and 8 frames; runs of 1, 3, 5, all; a run that starts
+    mid-half), with the pack threads on (4:2:0 1080p slots are > 4 MB) and off (small frames); a file that ends inside a
+    run is PQA_EINVAL, nothing of the half it hit is submitted, and the context stays usable; analyze-like chunking
+    through pipeline.score_files gives the same scores as before."""
+    import os
+    from pqa2_amd import _native as N
+    from pqa2_amd import pipeline, synth, yuvio
+    from pqa2_amd.engine import FeatureEngine
+    for w, h, bpc, n in ((322, 182, 8, 11), (1920, 1080, 8, 11), (640, 360, 10, 7)):
+        refs, diss = synth.make_clip(w, h, n, bpc, chroma=True)
+        info = synth.clip_info(w, h, bpc)
+        rp, dp = str(tmp_path / f"r_{w}.y4m"), str(tmp_path / f"d_{w}.y4m")
+        yuvio.write_y4m(rp, refs, info)
+        yuvio.write_y4m(dp, diss, info)
+        rr, dr = yuvio.open_video(rp), yuvio.open_video(dp)
+        rs, ds = rr.run_stride(0, n), dr.run_stride(0, n)
+        assert rs == info.frame_bytes + 6 and ds == rs
+        with FeatureEngine(w, h, bit_depth=bpc, n_planes=3, features=N.FEAT_ALL, max_batch=2) as eng:
+            for i in range(n):
+                eng.submit_file(i, rr.fileno(), rr.plane_offsets(i), dr.fileno(), dr.plane_offsets(i))
+            one = eng.collect(0, n)
+        for mb, runs in ((2, (1, 3, 5, n)), (8, (3, n))):
+            for run in runs:
+                with FeatureEngine(w, h, bit_depth=bpc, n_planes=3, features=N.FEAT_ALL, max_batch=mb) as eng:
+                    i = 0
+                    if run == 3:   # start mid-half: one single frame first
+                        eng.submit_file(0, rr.fileno(), rr.plane_offsets(0), dr.fileno(), dr.plane_offsets(0))
+                        i = 1
+                    while i < n:
+                        m = min(run, n - i)
+                        eng.submit_file_run(i, m, rr.fileno(), rr.plane_offsets(i), rs, dr.fileno(), dr.plane_offsets(i), ds)
+                        i += m
+                    got = eng.collect(0, n)
+                assert np.array_equal(one.view(np.uint64), got.view(np.uint64)), (w, mb, run)
+        # a reference file that ends inside frame 4: the run 2..6 fails, frames 0, 1 stay collectable, the context usable
+        short = str(tmp_path / f"short_{w}.y4m")
+        with open(rp, "rb") as f, open(short, "wb") as g:
+            g.write(f.read(rr.plane_offsets(4)[0] + 1000))
+        fd = os.open(short, os.O_RDONLY)
+        try:
+            with FeatureEngine(w, h, bit_depth=bpc, n_planes=3, features=N.FEAT_ALL, max_batch=8) as eng:
+                eng.submit_file_run(0, 2, fd, rr.plane_offsets(0), rs, dr.fileno(), dr.plane_offsets(0), ds)
+                with pytest.raises(N.PqaError) as e:
+                    eng.submit_file_run(2, 5, fd, rr.plane_offsets(2), rs, dr.fileno(), dr.plane_offsets(2), ds)
+                assert e.value.code == N.PQA_EINVAL and "short read" in str(e.value)
+                assert np.array_equal(eng.collect(0, 2).view(np.uint64), one[:2].view(np.uint64))
+                with pytest.raises(N.PqaError) as e:
+                    eng.collect(2, 1)                      # never submitted
+                assert e.value.code == N.PQA_ESTATE
+                eng.submit_file_run(2, n - 2, rr.fileno(), rr.plane_offsets(2), rs, dr.fileno(), dr.plane_offsets(2), ds)
+                assert np.array_equal(eng.collect(2, n - 2).view(np.uint64), one[2:].view(np.uint64))
+        finally:
+            os.close(fd)
+        if w == 322:   # the caller of the run entry point: score_files in runs of eight against frame by frame (PQA_FD_RUN=0)
+            res = pipeline.score_files(rp, dp, "vmaf_v0.6.1")
+            os.environ["PQA_FD_RUN"] = "0"
+            try:
+                res1 = pipeline.score_files(rp, dp, "vmaf_v0.6.1")
+            finally:
+                os.environ.pop("PQA_FD_RUN")
+            assert np.array_equal(res["records"].view(np.uint64), res1["records"].view(np.uint64))
