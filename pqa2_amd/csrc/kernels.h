@@ -117,8 +117,16 @@ inline int motion_tiles(int w, int h) {
 }
 // SAD of the 5-tap-blurred reference luma of frame f against frame f-1.  Frame 0 of the run uses
 // `prev0` (may be null: then its partials are zero).  partials: [n_frames][tiles] doubles.
+// mode (PQA_MOTION_MARCH, read once per context): MOTION_AUTO = the march kernel (motion_march.hip: one partial per wave
+// segment), MOTION_TILED = the LDS-tiled kernel (motion.hip: one per 252 x 16 tile; test partner and fallback for planes of
+// 2 GiB and more).  *n_partials (nullable) receives the number of partials per frame the launch wrote.
+enum : int { MOTION_TILED = 0, MOTION_AUTO = 1 };
 hipError_t launch_motion(hipStream_t stream, Elem elem, PlaneRun ref, const void* prev0, int64_t prev0_row_pitch,
-                         int n_frames, int w, int h, float inv_scale, double* partials);
+                         int n_frames, int w, int h, float inv_scale, double* partials, int mode = MOTION_AUTO,
+                         int* n_partials = nullptr);
+int motion_march_partials(int w, int h);   // partials per frame of the march kernel (workspace sizing; geometry only)
+bool launch_motion_march(hipStream_t stream, Elem elem, PlaneRun ref, const void* prev0, int64_t prev0_row_pitch, int n_frames,
+                         int w, int h, double* partials, int* n_partials, hipError_t* err);
 // Fixed-point motion (integer_motion.c arithmetic, motion_fixed.hip): partials are [n_frames][tiles] uint64 SADs of
 // the Q8 blurred planes.
 hipError_t launch_motion_fixed(hipStream_t stream, int bit_depth, Elem elem, PlaneRun ref, const void* prev0,

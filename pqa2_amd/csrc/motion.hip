@@ -126,8 +126,13 @@ __global__ __launch_bounds__(kBlock) void motion_kernel(const MotionArgs a) {
 }  // namespace
 
 hipError_t launch_motion(hipStream_t stream, Elem elem, PlaneRun ref, const void* prev0, int64_t prev0_row_pitch,
-                         int n_frames, int w, int h, float inv_scale, double* partials) {
+                         int n_frames, int w, int h, float inv_scale, double* partials, int mode, int* n_partials) {
+  if (n_partials) *n_partials = motion_tiles(w, h);
   if (n_frames <= 0) return hipSuccess;
+  if (mode == MOTION_AUTO) {
+    hipError_t err = hipSuccess;
+    if (launch_motion_march(stream, elem, ref, prev0, prev0_row_pitch, n_frames, w, h, partials, n_partials, &err)) return err;
+  }
   MotionArgs a{};
   a.ref = ref.base; a.row_pitch = ref.row_pitch; a.frame_pitch = ref.frame_pitch;
   a.prev0 = prev0; a.prev0_row_pitch = prev0_row_pitch;

@@ -163,6 +163,7 @@ struct pqa_ctx {
   bool multi_stream = false;
   int vif_s0_mode = VIF_S0_AUTO;   // PQA_VIF_MFMA, read once in pqa_create
   int adm_mode = ADM_AUTO;         // PQA_ADM_MARCH, read once in pqa_create
+  int motion_mode = MOTION_AUTO;   // PQA_MOTION_MARCH, read once in pqa_create
   bool trace = false;   // PQA_TRACE=1: synchronise after every launch and name it on stderr (localises a stall)
   bool prof = false;
   uint32_t prof_mask = 0xffffffffu;
@@ -332,6 +333,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   }
   int vif_np[4] = {c->vif_tiles[0], c->vif_tiles[1], c->vif_tiles[2], c->vif_tiles[3]};   // partial pairs written per frame
   int adm_np[4] = {c->adm_tiles[0], c->adm_tiles[1], c->adm_tiles[2], c->adm_tiles[3]};   // partial sextets written per frame
+  int motion_np = c->motion_tiles_n;                                                       // motion partials written per frame
 
   if ((feat & PQA_FEAT_VIF) && sp_n > 0 && c->vif_fixed) {
     PlaneRun cr = rYs, cd = dYs;
@@ -438,7 +440,8 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
       HIPCHK(c, launch_motion_fixed(st_misc, (int)c->cfg.bit_depth, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h,
                                     c->motion_fx_part));
     else
-      HIPCHK(c, launch_motion(st_misc, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h, c->inv_scale, c->motion_part));
+      HIPCHK(c, launch_motion(st_misc, c->elem, rY, p0, p0 ? p0_pitch / es : 0, n, w, h, c->inv_scale, c->motion_part,
+                              c->motion_mode, &motion_np));
   }
   int n_sse = 0, n_ssim = 0;
   bool sse_a[3] = {false, false, false}, sse_b[3] = {false, false, false}, sse_t[3] = {false, false, false};
@@ -501,7 +504,7 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     fa.adm_fx_num_shift[s] = c->adm_fx[s].num_row_shift; fa.adm_fx_den_shift[s] = c->adm_fx[s].den_row_shift;
   }
   fa.motion_part = c->motion_part;
-  fa.motion_tiles = c->motion_tiles_n;
+  fa.motion_tiles = c->motion_fixed ? c->motion_tiles_n : motion_np;
   fa.motion_norm = (double)c->inv_scale / ((double)w * h);
   fa.motion_fx_part = c->motion_fixed ? c->motion_fx_part : nullptr;
   fa.motion_wh = (unsigned)w * (unsigned)h;
@@ -884,6 +887,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     c->vif_s0_mode = (v && v[0] == '0') ? VIF_S0_VALU : VIF_S0_AUTO;
     const char* am = getenv("PQA_ADM_MARCH");  // 0: the LDS-tiled ADM kernel (A/B partner of the march kernel)
     c->adm_mode = (am && am[0] == '0') ? ADM_TILED : ADM_AUTO;
+    const char* mm = getenv("PQA_MOTION_MARCH");  // 0: the LDS-tiled motion kernel (test partner of the march kernel)
+    c->motion_mode = (mm && mm[0] == '0') ? MOTION_TILED : MOTION_AUTO;
   }
   for (int i = 0; i < 2; ++i) {
     CREATE_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
@@ -958,7 +963,10 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   }
   c->motion_tiles_n = motion_tiles(w, h);
   if (cfg->features & PQA_FEAT_MOTION) {
-    CREATE_TRY(dev_alloc(c, &c->motion_part, (size_t)c->motion_tiles_n * B));
+    {   // one partial per tile (motion.hip) or per wave segment (motion_march.hip)
+      const int mp = motion_march_partials(w, h);
+      CREATE_TRY(dev_alloc(c, &c->motion_part, (size_t)(c->motion_tiles_n > mp ? c->motion_tiles_n : mp) * B));
+    }
     if (c->motion_fixed) CREATE_TRY(dev_alloc(c, &c->motion_fx_part, (size_t)c->motion_tiles_n * B));
     c->last_luma_pitch = round_up((int64_t)w * c->esize, 64);
     CREATE_TRY(dev_alloc(c, &c->last_luma, (size_t)c->last_luma_pitch * h));

@@ -525,7 +525,8 @@ def test_worst_known_hd_flip_case_stays_bounded():
 
 @pytest.mark.parametrize("bpc", [8, 10])
 def test_march_kernel_takes_any_base_alignment_and_pitch_bit_for_bit(bpc):
-    """vif_s0_march_kernel loads 8 samples per lane with one 8 / 16-byte load when bases and pitches allow it and sample by
+    """(adm_march_kernel and motion_march_kernel -- two samples per lane and load -- are held to the same: round 4.)
+    vif_s0_march_kernel loads 8 samples per lane with one 8 / 16-byte load when bases and pitches allow it and sample by
     sample otherwise (and always for the stripes whose columns are mirrored).  A device-resident clip at base offsets 0..7
     samples into a padded allocation, with an odd pitch, and at widths that are not multiples of 16 must give the very same
     records as the packed, aligned clip -- the arithmetic does not depend on how the samples were fetched."""
@@ -549,10 +550,53 @@ def test_march_kernel_takes_any_base_alignment_and_pitch_bit_for_bit(bpc):
             vr[:, :, :w] = torch.from_numpy(R0).cuda()
             vd[:, :, :w] = torch.from_numpy(D0).cuda()
             torch.cuda.synchronize()
-            with FeatureEngine(w, h, bit_depth=bpc, features=N.FEAT_VIF | N.FEAT_MOTION) as eng:
+            with FeatureEngine(w, h, bit_depth=bpc, features=N.FEAT_VMAF) as eng:   # the ADM and motion march kernels too
                 eng.submit_resident(0, n, [vr.data_ptr()], [vd.data_ptr()], [pitch * es], [pitch * h * es])
                 return eng.collect(0, n)[:, :17]
         base = run(0, ((w + 15) // 16) * 16)
         for off, pitch in ((1, w), (3, w + 1), (4, w + 8), (7, ((w + 15) // 16) * 16)):
             got = run(off, pitch)
             assert np.array_equal(got.view(np.uint64), base.view(np.uint64)), (w, h, off, pitch)
+
+
+# ---- ADM and motion as register-only marches (adm_march.hip, motion_march.hip) vs the LDS-tiled kernels and the oracle ------
+@pytest.mark.parametrize("w,h,bpc", [(64, 48, 8), (200, 120, 8), (250, 40, 8), (489, 41, 8), (736, 488, 8), (1039, 913, 8),
+                                     (1920, 1080, 8), (322, 182, 10), (1281, 721, 10), (720, 486, 12)])
+def test_adm_and_motion_march_kernels_match_the_tiled_kernels_and_the_oracle(oracle32, w, h, bpc):
+    """The march kernels do the tiled kernels' arithmetic per coefficient / per pixel in the same order and differ only in
+    how the partial sums are grouped: they must agree to rounding (1e-6; measured 1e-8), PQA_ADM_MARCH=0 / PQA_MOTION_MARCH=0
+    (read at pqa_create) must really switch them off, and both must sit inside the oracle bar.  Geometries: one EDGE stripe
+    only, two stripes, a fast stripe between two edge stripes, odd sizes (mirrored last column / row), segment boundaries
+    inside and outside the 10 % crop, deep scales down to a few coefficients, 8 / 10 / 12 bit."""
+    import os
+    from pqa2_amd import synth
+    from pqa2_amd.engine import FeatureEngine
+    from pqa2_amd import _native as N
+    n = 3
+    refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
+
+    def run(**env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with FeatureEngine(w, h, bit_depth=bpc, features=N.FEAT_ADM | N.FEAT_MOTION, max_batch=2) as eng:
+                for i in range(n):
+                    eng.submit(i, refs[i], diss[i])
+                return eng.collect(0, n)[:, 8:17]
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    march = run()
+    tiled = run(PQA_ADM_MARCH="0", PQA_MOTION_MARCH="0")
+    assert not np.array_equal(march[:, :8].view(np.uint64), tiled[:, :8].view(np.uint64)), "PQA_ADM_MARCH=0 did not change the path"
+    assert not np.array_equal(march[1:, 8].view(np.uint64), tiled[1:, 8].view(np.uint64)), "PQA_MOTION_MARCH=0 did not change the path"
+    assert march[0, 8] == 0.0 and tiled[0, 8] == 0.0
+    den = np.maximum(np.abs(tiled), 1e-30)
+    assert (np.abs(march - tiled) / den).max() < 1e-6, (np.abs(march - tiled) / den).max()
+    exp = oracle32.clip_features([r[0] for r in refs], [d[0] for d in diss], bpc)[:, 8:17]
+    assert (np.abs(march[:, :8] - exp[:, :8]) / np.abs(exp[:, :8])).max() < REL_TOL
+    assert np.abs(march[:, 8] - exp[:, 8]).max() < 2e-5
