@@ -344,7 +344,7 @@ hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun r
                             MutPlaneRun ll_dis, double* partials, int mode, int* n_partials) {
   if (n_partials) *n_partials = adm_tiles_x((w + 1) / 2) * adm_tiles_y((h + 1) / 2);
   if (n_frames <= 0) return hipSuccess;
-  if (mode == ADM_AUTO) {
+  if (mode != ADM_TILED) {
     hipError_t err = hipSuccess;
     if (launch_adm_march(stream, scale, elem, ref, dis, n_frames, w, h, inv_scale, gain_limit, ll_ref, ll_dis, partials,
                          n_partials, &err))

@@ -28,6 +28,7 @@
 // two-sample loads take the EDGE instantiation: one load per sample with mirrored column indices.
 #include <type_traits>
 
+#include "adm_chain.h"
 #include "kernels.h"
 #include "pqa_device.h"
 
@@ -57,40 +58,8 @@ struct AdmMarchArgs {
   int n_part;
 };
 
-constexpr float kLo0 = 0.482962913144690f, kLo1 = 0.836516303737469f, kLo2 = 0.224143868041857f, kLo3 = -0.129409522550921f;
-constexpr float kHi0 = -0.129409522550921f, kHi1 = -0.224143868041857f, kHi2 = 0.836516303737469f, kHi3 = -0.482962913144690f;
+using namespace admc;
 
-__device__ __forceinline__ f2 splat2(float c) { return f2{c, c}; }
-// taps accumulate in libvmaf's order: ((c0*s0 + c1*s1) + c2*s2) + c3*s3
-__device__ __forceinline__ f2 dwt_lo(f2 t0, f2 t1, f2 t2, f2 t3) {
-  return __builtin_elementwise_fma(splat2(kLo3), t3,
-                                   __builtin_elementwise_fma(splat2(kLo2), t2, __builtin_elementwise_fma(splat2(kLo1), t1, splat2(kLo0) * t0)));
-}
-__device__ __forceinline__ f2 dwt_hi(f2 t0, f2 t1, f2 t2, f2 t3) {
-  return __builtin_elementwise_fma(splat2(kHi3), t3,
-                                   __builtin_elementwise_fma(splat2(kHi2), t2, __builtin_elementwise_fma(splat2(kHi1), t1, splat2(kHi0) * t0)));
-}
-
-// lane l <- lane l - 1 (wave_shr:1) / lane l + 1 (wave_shl:1) across the whole wave; the end lanes read 0
-__device__ __forceinline__ float from_left(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float from_right(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
-__device__ __forceinline__ f2 from_left(f2 v) { return f2{from_left(v.x), from_left(v.y)}; }
-__device__ __forceinline__ f2 from_right(f2 v) { return f2{from_right(v.x), from_right(v.y)}; }
-
-// (the value goes through a by-value float parameter: __builtin_bit_cast applied directly to a vector ELEMENT expression
-// compiled to the vector's first element on this toolchain -- both stores of a {ref, dis} pair wrote .x)
-__device__ __forceinline__ void store_f32(const float v, const rsrc_t rs, const unsigned voff, const unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
-}
-
-// One input row of the lane: columns 2c and 2c + 1, each {ref, dis}
-struct Row {
-  f2 c0, c1;
-};
 // The same as loaded (before conversion): what a prefetch keeps in registers for one row and BOTH images
 template <typename T, bool EDGE> struct RawRow;
 template <> struct RawRow<uint8_t, false> { unsigned r, d; };          // two bytes each
@@ -146,16 +115,11 @@ struct RowLoader {
   }
 };
 
-// What row i leaves behind until row i + 1's masking sum exists: the restored coefficients, the centre of the masking box
-struct Pending {
-  float rh, rv, rd, g;
-};
-
 template <typename T, bool EDGE>
 __device__ __forceinline__ void march_full(const AdmMarchArgs& a, const RowLoader<T, EDGE>& ld, const int lane, const int cs,
                                            const int r0, const int r1, float* __restrict__ ll_r, float* __restrict__ ll_d,
                                            const unsigned ll_voff, double* __restrict__ part) {
-  const float cos_1deg_sq = 0.99969541350954788f;  // cos(pi/180)^2
+  const Consts K{a.gain_limit, a.rf_hv, a.rf_d, a.k_hv, a.k_d};
   const rsrc_t ll_rs_r = make_rsrc(ll_r, ll_r ? (unsigned)a.oh * a.ll_pitch_r * 4u : 0u);
   const rsrc_t ll_rs_d = make_rsrc(ll_d, ll_d ? (unsigned)a.oh * a.ll_pitch_d * 4u : 0u);
   // (last scale: no approximation band is owed; the resource then has zero records and every store is dropped -- cheaper
@@ -185,18 +149,7 @@ __device__ __forceinline__ void march_full(const AdmMarchArgs& a, const RowLoade
       store_f32(ba.x, ll_rs_r, ll_voff, (unsigned)i * a.ll_pitch_r * 4u);
       store_f32(ba.y, ll_rs_d, ll_voff, (unsigned)i * a.ll_pitch_d * 4u);
     }
-    const float oh = bh.x, th = bh.y, ov = bv.x, tv = bv.y, od = bd.x, td = bd.y;
-    // decouple + enhancement-gain limit as one median per orientation (adm.hip explains the identity)
-    const float ot_dp = fmaf(ov, tv, oh * th);
-    const f2 mag = __builtin_elementwise_fma(bv, bv, bh * bh);   // {|o|^2, |t|^2}
-    const float lhs = ot_dp * ot_dp, rhs = cos_1deg_sq * mag.x * mag.y;
-    const bool ang = (ot_dp >= 0.0f) && (lhs >= rhs);
-    const float m = ang ? a.gain_limit : 1.0f;
-    p.rh = __builtin_amdgcn_fmed3f(0.0f, th, oh * m);
-    p.rv = __builtin_amdgcn_fmed3f(0.0f, tv, ov * m);
-    p.rd = __builtin_amdgcn_fmed3f(0.0f, td, od * m);
-    const float ah = th - p.rh, av = tv - p.rv, ad = td - p.rd;
-    float g = fmaf(a.k_d, fabsf(ad), a.k_hv * (fabsf(ah) + fabsf(av)));
+    float g = decouple(bh, bv, bd, K, p);
     if (EDGE) {
       if (fix_left) {
         const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), lane_m1));
@@ -208,24 +161,10 @@ __device__ __forceinline__ void march_full(const AdmMarchArgs& a, const RowLoade
       }
     }
     p.g = g;
-    if (OWN) {   // denominator: sum |rf o|^3 = rf^3 sum |o|^3 -- the CSF factor is applied to the wave's sum
-      acc[3] = fmaf(oh * oh, fabsf(oh), acc[3]);
-      acc[4] = fmaf(ov * ov, fabsf(ov), acc[4]);
-      acc[5] = fmaf(od * od, fabsf(od), acc[5]);
-    }
+    if (OWN) den_accumulate(bh, bv, bd, acc + 3);
     return (from_left(g) + g) + from_right(g);
   };
-  // finish the row whose pending values are p: threshold = 3x3 box of the masking signal + centre.  A pending set of zeros
-  // (what the row above the segment leaves) contributes exactly 0: x = max(-thr, 0) with thr >= 0.
-  const auto finish = [&](const Pending& p, const float s2 /* sums of the row above and of the row itself */, const float rs_below) {
-    const float thr = (s2 + rs_below) + p.g;
-    const float xh = fmaxf(fmaf(fabsf(p.rh), a.rf_hv, -thr), 0.0f);
-    const float xv = fmaxf(fmaf(fabsf(p.rv), a.rf_hv, -thr), 0.0f);
-    const float xd = fmaxf(fmaf(fabsf(p.rd), a.rf_d, -thr), 0.0f);
-    acc[0] = fmaf(xh * xh, xh, acc[0]);
-    acc[1] = fmaf(xv * xv, xv, acc[1]);
-    acc[2] = fmaf(xd * xd, xd, acc[2]);
-  };
+  const auto finish_row = [&](const Pending& p, const float s2, const float rs_below) { finish(p, s2, rs_below, K, acc); };
   const auto flush = [&]() {
 #pragma unroll
     for (int q = 0; q < 6; ++q) { dacc[q] += (double)acc[q]; acc[q] = 0.0f; }
@@ -257,7 +196,7 @@ __device__ __forceinline__ void march_full(const AdmMarchArgs& a, const RowLoade
     n0 = ld.convert(q0); n1 = ld.convert(q1);
     if (decltype(is_own)::value) { q0 = ld.load(2 * i + 5); q1 = ld.load(2 * i + 6); }   // row i + 2's new rows
     const float rs = row(c0, c1, n0, n1, i, is_own, mine);
-    finish(above, s2, rs);
+    finish_row(above, s2, rs);
     s2 = rs_prev + rs;
     rs_prev = rs;
   };
@@ -275,7 +214,7 @@ __device__ __forceinline__ void march_full(const AdmMarchArgs& a, const RowLoade
   if (r1 < a.oh) {
     step(w2, w3, w0, w1, pa, pb, qa0, qa1, r1, guest);
   } else {
-    finish(pa, s2, rs_prev);
+    finish_row(pa, s2, rs_prev);
   }
   flush();
   // column mask once per wave: the lane has a column of its own inside [left, right)

@@ -74,10 +74,10 @@ inline int adm_tiles_y(int band_h) { return (band_h + kAdmTileH - 1) / kAdmTileH
 // partials: [n_frames][tiles][6] doubles (num h,v,d cube sums; den h,v,d cube sums).
 // ll_ref/ll_dis receive the approximation band (ceil(w/2) x ceil(h/2)) for the next scale
 // (base may be null at the last scale).
-// mode (read once per context from PQA_ADM_MARCH in pqa_create): ADM_AUTO = the march kernel (adm_march.hip: one partial
+// mode (read once per context from PQA_ADM_MARCH / PQA_ADM_PYRAMID in pqa_create): ADM_AUTO = the march kernel (adm_march.hip: one partial
 // sextet per wave segment), ADM_TILED = the LDS-tiled kernel (adm.hip: one per 60 x 14 tile; A/B partner, and the fallback
 // for planes of 2 GiB and more).  *n_partials (nullable) receives the number of sextets per frame the launch wrote.
-enum : int { ADM_TILED = 0, ADM_AUTO = 1 };
+enum : int { ADM_TILED = 0, ADM_AUTO = 1, ADM_MARCH = 2 };   // ADM_MARCH: the march kernel, one scale per launch (no pyramid)
 hipError_t launch_adm_scale(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                             int w, int h, float inv_scale, float gain_limit, MutPlaneRun ll_ref,
                             MutPlaneRun ll_dis, double* partials, int mode = ADM_AUTO, int* n_partials = nullptr);
@@ -87,6 +87,15 @@ int adm_march_partials(int band_w, int band_h);
 bool launch_adm_march(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h,
                       float inv_scale, float gain_limit, MutPlaneRun ll_ref, MutPlaneRun ll_dis, double* partials,
                       int* n_partials, hipError_t* err);
+// Scales 0 and 1 in ONE launch (adm_pyramid.hip): scale 0's approximation band stays in registers; partials0 / partials1
+// receive one sextet per wave segment each (the same count, *n_partials), ll_ref / ll_dis the approximation band of SCALE 1
+// (w/4 x h/4: the input of scale 2).  adm_pyramid_takes: u8 / u16 planes whose width and height are multiples of 4 and >= 128;
+// launch_adm_pyramid returns false when it cannot take the planes (the caller then runs one scale per launch).
+bool adm_pyramid_takes(Elem elem, int w, int h);
+int adm_pyramid_partials(int w, int h);
+bool launch_adm_pyramid(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float inv_scale,
+                        float gain_limit, MutPlaneRun ll_ref, MutPlaneRun ll_dis, double* partials0, double* partials1,
+                        int* n_partials, hipError_t* err);
 float adm_dwt_quant_step(int lambda, int theta);   // Watson model step (adm_tools.h dwt_quant_step), theta 1 = h/v, 2 = d
 
 // Fixed-point ADM (integer_adm.c arithmetic, adm_fixed.hip).  Same tiling as launch_adm_scale; the approximation

@@ -413,7 +413,25 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
     PlaneRun cr = rYs, cd = dYs;
     Elem ce = c->elem;
     int cw = w, ch = h;
-    for (int s = 0; s < 4; ++s) {
+    int s = 0;
+    if (c->adm_mode == ADM_AUTO) {   // scales 0 and 1 in one launch when the geometry allows (adm_pyramid.hip)
+      Level& L2 = c->adm_lv[2];
+      hipError_t perr = hipSuccess;
+      int np = 0;
+      ProfScope ps(c, 7, sp_n, st_adm);
+      if (launch_adm_pyramid(st_adm, ce, cr, cd, sp_n, cw, ch, c->inv_scale, (float)c->cfg.adm_enhn_gain_limit,
+                             MutPlaneRun{L2.ref, L2.pitch, L2.frame_pitch}, MutPlaneRun{L2.dis, L2.pitch, L2.frame_pitch},
+                             c->adm_part[0], c->adm_part[1], &np, &perr)) {
+        HIPCHK(c, perr);
+        adm_np[0] = adm_np[1] = np;
+        cr = PlaneRun{L2.ref, L2.pitch, L2.frame_pitch};
+        cd = PlaneRun{L2.dis, L2.pitch, L2.frame_pitch};
+        ce = ELEM_F32;
+        cw = L2.w; ch = L2.h;
+        s = 2;
+      }
+    }
+    for (; s < 4; ++s) {
       MutPlaneRun lr{nullptr, 0, 0}, ld{nullptr, 0, 0};
       if (s < 3) {
         Level& L = c->adm_lv[s + 1];
@@ -886,7 +904,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     const char* v = getenv("PQA_VIF_MFMA");   // 0: VALU kernels only (the march kernel's test partner); default: march kernel
     c->vif_s0_mode = (v && v[0] == '0') ? VIF_S0_VALU : VIF_S0_AUTO;
     const char* am = getenv("PQA_ADM_MARCH");  // 0: the LDS-tiled ADM kernel (A/B partner of the march kernel)
-    c->adm_mode = (am && am[0] == '0') ? ADM_TILED : ADM_AUTO;
+    const char* ap = getenv("PQA_ADM_PYRAMID");  // 0: the march kernel one scale per launch (test partner of the pyramid kernel)
+    c->adm_mode = (am && am[0] == '0') ? ADM_TILED : (ap && ap[0] == '0') ? ADM_MARCH : ADM_AUTO;
     const char* mm = getenv("PQA_MOTION_MARCH");  // 0: the LDS-tiled motion kernel (test partner of the march kernel)
     c->motion_mode = (mm && mm[0] == '0') ? MOTION_TILED : MOTION_AUTO;
   }
@@ -955,7 +974,8 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
       CREATE_TRY(dev_alloc(c, &c->vif_fx_part[s], (size_t)c->vif_tiles[s] * kVifFxPartials * B));
     c->adm_fx[s] = adm_fixed_scale_params(s, bw, bh);
     if ((cfg->features & PQA_FEAT_ADM) && !c->adm_fixed) {   // one sextet per tile (adm.hip) or per wave segment (adm_march.hip)
-      const int mp = adm_march_partials(bw, bh);
+      int mp = adm_march_partials(bw, bh);
+      if (s < 2 && adm_pyramid_takes(c->elem, w, h)) { const int pp = adm_pyramid_partials(w, h); mp = pp > mp ? pp : mp; }
       CREATE_TRY(dev_alloc(c, &c->adm_part[s], (size_t)(c->adm_tiles[s] > mp ? c->adm_tiles[s] : mp) * 6 * B));
     }
     if ((cfg->features & PQA_FEAT_ADM) && c->adm_fixed)
