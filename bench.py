@@ -296,6 +296,22 @@ def main():
             out["kernel_ms_per_frame"] = {name: round(v["ms"] / max(1, v["frames"]), 5)
                                           for name, v in breakdown.items() if v["launches"]}
             out["kernel_ms_note"] = "from one extra untimed pass with every kernel event-timed (ms per frame)"
+            # the second-largest launch since round 4: ADM scales 0 + 1 in one kernel (csrc/adm_pyramid.hip), which -- unlike VIF
+            # scale 0 -- sits on the memory side.  Same accounting: algorithmic bytes (the luma pair once) over its event time.
+            ka = breakdown.get("adm_scale_s0")
+            if ka and ka["launches"] and not (args.fixed_point & 4):
+                a_ms = ka["ms"] / ka["launches"]
+                a_fpl = ka["frames"] / ka["launches"]
+                a_ach = b_alg * a_fpl / (a_ms * 1e-3) / 1e9
+                fused = "adm_scale_s1" not in breakdown or not breakdown["adm_scale_s1"]["launches"]
+                ca = _kernel_counters(args.workload, "adm_s0")
+                out["roofline_adm"] = {"bound": "hbm", "kernel": ("adm_pyramid_kernel (ADM scales 0 + 1 in one launch)" if fused
+                                                                 else "adm_march_kernel (ADM scale 0)"),
+                                       "achieved": round(a_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(a_ach / HBM_PEAK_GBS, 5), "avg_launch_ms": round(a_ms, 4),
+                                       "traffic": int(ca["hbm_bytes_per_frame"] * a_fpl) if ca.get("hbm_bytes_per_frame") else None,
+                                       "traffic_source": ca.get("traffic_source"),
+                                       "timed": "breakdown pass (one stream, every kernel event-timed), not the timed region"}
 
         if world == 1 and not args.no_cpu_baseline and not args.fixed_point:  # the CPU leg times the float restatement
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
@@ -463,21 +479,25 @@ def _bookend_leg():
         return {"error": (str(e) or "failed")[:200]}
 
 
-def kernel_source_hash() -> str:
-    """sha256 over the sources of the dominant kernel (VIF scale 0): counters measured for another version of it are stale.
-    Covers the VIF kernel files, the shared device helpers and the VIF section of kernels.h (tile geometry, launcher
-    contracts) -- not the declarations of unrelated kernels in that header."""
+def kernel_source_hash(group: str = "vif") -> str:
+    """sha256 over the sources of a kernel whose committed counters bench.py quotes: counters measured for another version
+    of it are stale.  "vif" (the dominant kernel, VIF scale 0): the VIF kernel files, the shared device helpers and the VIF
+    section of kernels.h (tile geometry, launcher contracts) -- not the declarations of unrelated kernels in that header.
+    "adm": the ADM march / pyramid kernels and their shared chain."""
     import hashlib
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "pqa2_amd", "csrc")
     # the scale-0 kernels live in vif.hip / vif_march.hip; march_common.h holds the march kernel's splits and MFMA wrappers
-    for f in ("vif.hip", "vif_march.hip", "march_common.h", "pqa_device.h"):
+    files = {"vif": ("vif.hip", "vif_march.hip", "march_common.h", "pqa_device.h"),
+             "adm": ("adm_pyramid.hip", "adm_march.hip", "adm_chain.h", "adm.hip", "pqa_device.h")}[group]
+    for f in files:
         if os.path.exists(os.path.join(d, f)):
             with open(os.path.join(d, f), "rb") as fh:
                 hsh.update(fh.read())
     with open(os.path.join(d, "kernels.h"), "rb") as fh:
         k = fh.read()
-    a, b = k.find(b"// ---- VIF"), k.find(b"// ---- ADM")
+    marks = {"vif": (b"// ---- VIF", b"// ---- ADM"), "adm": (b"// ---- ADM", b"// ---- motion")}[group]
+    a, b = k.find(marks[0]), k.find(marks[1])
     hsh.update(k[a:b] if 0 <= a < b else k)
     return hsh.hexdigest()[:16]
 
@@ -494,9 +514,10 @@ def _kernel_counters(workload: str, kernel: str) -> dict:
         return {}
     if not d:
         return {}
-    if d.get("src_hash") != kernel_source_hash():
+    now = kernel_source_hash("adm" if kernel.startswith("adm") else "vif")
+    if d.get("src_hash") != now:
         return {"traffic_source": f"{d.get('traffic_source', p)} is for kernel source {d.get('src_hash')}, the kernel has "
-                                  f"changed since (now {kernel_source_hash()}): dropped as stale"}
+                                  f"changed since (now {now}): dropped as stale"}
     return d
 
 

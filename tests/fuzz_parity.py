@@ -47,6 +47,8 @@ while time.time() - t0 < budget:
         w, h = int(rng.integers(900, 1930)), int(rng.integers(540, 1090))
     else:
         w, h = int(rng.integers(16, 700)), int(rng.integers(16, 400))
+    if rng.integers(0, 3) == 0:   # multiples of 4 (from 128 up) take the ADM pyramid kernel: make sure they come up
+        w, h = max(16, w & ~3), max(16, h & ~3)
     bpc = int(rng.choice([8, 8, 8, 10, 12]))
     peak = (1 << bpc) - 1
     kind = int(rng.integers(0, 5))

@@ -279,6 +279,9 @@ def test_committed_kernel_counters_match_the_kernel_source():
         assert e["src_hash"] == bench.kernel_source_hash(), f"profiles/kernel_counters.json[{wl}] is stale: re-run tools/profile_round.sh"
         assert e["hbm_bytes_per_frame"] > b_alg and e["valu_wave_insts_per_frame"] > 0
         assert os.path.exists(os.path.join(root, e["traffic_source"].split(" ")[0]))
+        adm = d[wl]["adm_s0"]   # bench.py's `roofline_adm` (the memory-side half of the frame since round 4)
+        assert adm["src_hash"] == bench.kernel_source_hash("adm"), f"profiles/kernel_counters.json[{wl}].adm_s0 is stale: re-run tools/profile_round.sh"
+        assert adm["hbm_bytes_per_frame"] > b_alg
 
 
 _FAKE_FFMPEG = r'''#!/usr/bin/env python3

@@ -125,5 +125,13 @@ if pmc:
                           "shader_clock_ghz": round(sq.get("clock_ghz", 2.0), 3),
                           "valu_source": f"profiles/{a.tag}_sq_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES of the scale-0 launches, committed)"})
         cur.setdefault(a.workload, {})["vif_stat_s0"] = e
+        # the ADM launch that reads the luma pair (adm_pyramid_kernel: scales 0 + 1; adm_march_kernel / adm_scale_kernel of the
+        # sample type: scale 0 alone): its traffic for bench.py's `roofline_adm`
+        adm = [k for k in pmc if k.startswith((f"adm_pyramid_kernel<{ty}", f"adm_march_kernel<{ty}", f"adm_scale_kernel<{ty}"))]
+        if adm:
+            ka = max(adm, key=lambda k: pmc[k]["hbm_bytes_per_frame_corrected"])
+            cur[a.workload]["adm_s0"] = {"kernel": ka, "hbm_bytes_per_frame": int(pmc[ka]["hbm_bytes_per_frame_corrected"]),
+                                         "src_hash": kernel_source_hash("adm"),
+                                         "traffic_source": f"profiles/{a.tag}_pmc.json (committed rocprofv3 --pmc passes, not this run)"}
         json.dump(cur, open(tj, "w"), indent=1)
 print("ok")
