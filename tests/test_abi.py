@@ -148,3 +148,27 @@ def test_march_kernels_fit_three_waves_per_simd_without_scratch(tmp_path):
     assert len(scratch) >= 2 and all(s == 0 for s in scratch), scratch          # the 8-bit and the 10-bit instance
     assert all(v <= 168 for v in vgprs), vgprs                                   # 512 / 3 waves, 8-register granules
     assert "Folded Reload" not in text and "Folded Spill" not in text
+
+
+def test_round4_march_kernels_keep_their_occupancy_without_scratch(tmp_path):
+    """adm_pyramid_kernel carries two scales' state per lane; its per-thread double sums were moved to LDS precisely so that
+    it fits three waves per SIMD (<= 168 VGPRs) without spilling -- with them in registers the compiler spilled 36 dwords at
+    three waves and two waves measured 5 % slower.  adm_march_kernel and motion_march_kernel hide their memory latency with
+    five-plus waves per SIMD (<= 96 VGPRs) and must never touch scratch (the f32 EDGE path once did: register shuffling
+    through scratch_store_dwordx3).  Built with the flags build.sh uses for these files."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    for name, max_vgprs, n_inst in (("adm_pyramid", 168, 2), ("adm_march", 96, 3), ("motion_march", 96, 2)):
+        src = os.path.join(ROOT, "pqa2_amd", "csrc", name + ".hip")
+        out = tmp_path / (name + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", src,
+                        "-o", str(out)], check=True, capture_output=True)
+        text = out.read_text()
+        scratch = [int(x) for x in re.findall(r"^; ScratchSize: (\d+)", text, re.M)]
+        vgprs = [int(x) for x in re.findall(r"^; TotalNumVgprs: (\d+)", text, re.M)]
+        assert len(scratch) >= n_inst and all(s == 0 for s in scratch), (name, scratch)
+        assert all(v <= max_vgprs for v in vgprs), (name, vgprs)
+        assert "Folded Reload" not in text and "Folded Spill" not in text, name
