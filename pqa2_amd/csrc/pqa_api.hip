@@ -160,7 +160,7 @@ struct pqa_ctx {
   std::string err;
   std::vector<void*> allocs;
   // profiling
-  bool multi_stream = false;
+  int multi_stream = 0;              // 0 one stream; 1 three streams from the start of a batch; 2 three streams behind VIF scale 0
   int vif_s0_mode = VIF_S0_AUTO;   // PQA_VIF_MFMA, read once in pqa_create
   int adm_mode = ADM_AUTO;         // PQA_ADM_MARCH, read once in pqa_create
   int motion_mode = MOTION_AUTO;   // PQA_MOTION_MARCH, read once in pqa_create
@@ -302,12 +302,9 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   // (with EVERY kernel event-timed -- the breakdown pass of bench.py -- the chains stay on one stream, so that a kernel's
   // figure is its own and not its share of a crowded device; a subset mask, as in the timed region, changes nothing)
   const bool multi = c->multi_stream && !(c->prof && c->prof_mask == 0xffffffffu);
+  // mode 2: the other chains start behind VIF scale 0 (the dominant launch runs alone, its figures stay its own) and
+  // overlap VIF scales 1-3 only; the fork event is then recorded right after that launch
   hipStream_t st_adm = multi ? c->aux[0] : st, st_misc = multi ? c->aux[1] : st;
-  if (multi) {
-    HIPCHK(c, hipEventRecord(c->fork_ev, st));
-    HIPCHK(c, hipStreamWaitEvent(st_adm, c->fork_ev, 0));
-    HIPCHK(c, hipStreamWaitEvent(st_misc, c->fork_ev, 0));
-  }
 
   // frames that get spatial features (libvmaf n_subsample: index % k == 0)
   const int k = c->k_sub;
@@ -315,6 +312,12 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
   if (k > 1) {
     e0 = (int)((k - first % k) % k);
     sp_n = e0 < n ? (n - e0 + k - 1) / k : 0;
+  }
+  const bool fork_late = multi && c->multi_stream == 2 && (feat & PQA_FEAT_VIF) && !c->vif_fixed && sp_n > 0;
+  if (multi && !fork_late) {
+    HIPCHK(c, hipEventRecord(c->fork_ev, st));
+    HIPCHK(c, hipStreamWaitEvent(st_adm, c->fork_ev, 0));
+    HIPCHK(c, hipStreamWaitEvent(st_misc, c->fork_ev, 0));
   }
   const auto sub = [&](PlaneRun r) {
     return PlaneRun{(const uint8_t*)r.base + (int64_t)e0 * r.frame_pitch * es, r.row_pitch, r.frame_pitch * k};
@@ -375,6 +378,11 @@ int process_batch(pqa_ctx* c, int64_t first, int n, const pqa_device_clip* ref, 
         HIPCHK(c, launch_vif_stat(st, s, ce, cr, cd, sp_n, cw, ch, c->inv_scale,
                                   (float)c->cfg.vif_enhn_gain_limit, c->cfg.vif_border == PQA_VIF_BORDER_INTEGER,
                                   c->vif_part[s], nr, nd, c->vif_s0_mode, &vif_np[s]));
+      }
+      if (s == 0 && fork_late) {
+        HIPCHK(c, hipEventRecord(c->fork_ev, st));
+        HIPCHK(c, hipStreamWaitEvent(st_adm, c->fork_ev, 0));
+        HIPCHK(c, hipStreamWaitEvent(st_misc, c->fork_ev, 0));
       }
       if (s < 3) {
         Level& L = c->vif_lv[s + 1];
@@ -898,7 +906,7 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     // r04j_prio.txt) -- but a kernel's launch then lasts as long as its share of a crowded device allows (VIF scale 0: 1.23 ms
     // instead of 0.76), so the per-kernel figures stop describing the kernels; stream priorities changed nothing.  Off by default.
     const char* e = getenv("PQA_MULTI_STREAM");
-    c->multi_stream = e && e[0] == '1';
+    c->multi_stream = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 0;
     const char* t = getenv("PQA_TRACE");
     c->trace = t && t[0] == '1';
     const char* v = getenv("PQA_VIF_MFMA");   // 0: VALU kernels only (the march kernel's test partner); default: march kernel
