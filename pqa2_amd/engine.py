@@ -7,10 +7,41 @@ array.  All arithmetic happens in the HIP kernels behind the C ABI (include/pqa_
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _native as N
+
+
+_PARKED = {}   # at most one entry: configuration bytes -> (library, context) parked by FeatureEngine.release()
+
+
+def _take_parked(key):
+    hit = _PARKED.pop(key, None)
+    return hit[1] if hit else None
+
+
+def clear_parked():
+    """Destroy the context FeatureEngine.release() parked (also runs at interpreter exit)."""
+    while _PARKED:
+        _, (lib, ctx) = _PARKED.popitem()
+        try:
+            lib.pqa_destroy(ctx)
+        except Exception:
+            pass
+
+
+def _park(lib, key, ctx):
+    clear_parked()            # one per process: whatever was parked before goes
+    if not _PARKED_HOOK:
+        import atexit
+        atexit.register(clear_parked)
+        _PARKED_HOOK.append(True)
+    _PARKED[key] = (lib, C.c_void_p(ctx.value))
+
+
+_PARKED_HOOK = []
 
 
 class FeatureEngine:
@@ -18,7 +49,7 @@ class FeatureEngine:
                  chroma_shift=(1, 1), features: int = N.FEAT_VMAF, device: int = 0, max_batch: int = 0,
                  result_capacity: int = 16384, n_subsample: int = 1,
                  vif_enhn_gain_limit: float = 100.0, adm_enhn_gain_limit: float = 100.0,
-                 vif_border: int = N.VIF_BORDER_FLOAT, fixed_point: int = 0):
+                 vif_border: int = N.VIF_BORDER_FLOAT, fixed_point: int = 0, reuse: bool = False):
         self.lib = N.load()
         cfg = N.PqaConfig()
         self.lib.pqa_config_init(C.byref(cfg), width, height)
@@ -39,6 +70,14 @@ class FeatureEngine:
         self.dtype = np.uint8 if bit_depth <= 8 else np.dtype("<u2")
         self._ctx = C.c_void_p()
         self.luma_gray = N.GRAY_LUMA   # mirror of the context's sticky gray mode (pqa_set_luma_gray)
+        self._key = bytes(cfg)         # every field of the configuration: what a parked context must match
+        parked = _take_parked(self._key) if reuse else None
+        if parked is not None:         # a context release() parked: same configuration, back to its initial state
+            self._ctx = parked
+            if self.lib.pqa_reset(self._ctx) == N.PQA_OK and self.lib.pqa_set_luma_gray(self._ctx, N.GRAY_LUMA) == N.PQA_OK:
+                return
+            self.lib.pqa_destroy(self._ctx)
+            self._ctx = C.c_void_p()
         rc = self.lib.pqa_create(C.byref(cfg), C.byref(self._ctx))
         if rc != N.PQA_OK:
             raise N.PqaError(rc, (self.lib.pqa_last_error(None) or b"").decode())
@@ -48,6 +87,19 @@ class FeatureEngine:
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
             self.lib.pqa_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+    def release(self):
+        """Like close(), but a healthy context is PARKED for the next FeatureEngine(..., reuse=True) of the very same
+        configuration instead of being destroyed (the reference's caller makes a fresh analyzer per run,
+        app/ui/tabs/analysis_tab.py:588: creating and destroying a 2160p context costs ~7 ms of a 180 ms analysis).  One
+        context per process is kept; it is destroyed when another one is parked, by clear_parked(), or at interpreter exit.
+        PQA_CONTEXT_CACHE=0 turns parking off.  Call only after a successful run: a context that reported an error is closed."""
+        if getattr(self, "_ctx", None) is None or not self._ctx.value:
+            return
+        if os.environ.get("PQA_CONTEXT_CACHE", "1") == "0":
+            return self.close()
+        _park(self.lib, self._key, self._ctx)
+        self._ctx = C.c_void_p()
 
     def __del__(self):
         try:

@@ -51,7 +51,7 @@ def score_files(reference_path: str, distorted_path: str, model: str | None = "v
     a, b = shard.shard_bounds(n, world_size, rank)
     t_start = time.perf_counter()
 
-    make = engine_factory or FeatureEngine
+    make = engine_factory or (lambda *aa, **kw: FeatureEngine(*aa, reuse=True, **kw))   # a parked context of this configuration
     eng = make(ri.width, ri.height, bit_depth=ri.bit_depth, n_planes=n_planes,
                chroma_shift=(ri.hshift, ri.vshift), features=feats, device=device, max_batch=max_batch,
                result_capacity=max(b - a, 16), n_subsample=n_subsample,
@@ -89,8 +89,10 @@ def score_files(reference_path: str, distorted_path: str, model: str | None = "v
             if progress is not None:
                 progress(i - a, b - a)
         local = eng.collect(a, b - a) if b > a else np.zeros((0, N.RECORD_DOUBLES))
-    finally:
+    except BaseException:
         eng.close()
+        raise
+    (eng.release if hasattr(eng, "release") else eng.close)()   # healthy: parked for the next analysis of this geometry
     rec = shard.gather_records(local, n, world_size, rank, gather_device)
     if rank != 0:
         return None

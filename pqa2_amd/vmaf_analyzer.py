@@ -24,6 +24,7 @@ import time
 from datetime import datetime
 
 logger = logging.getLogger(__name__)
+_METADATA_CACHE = {}   # (abspath, size, mtime_ns) -> metadata dict of get_video_metadata
 
 try:  # pragma: no cover - PyQt5 is not installed in the build container
     from PyQt5.QtCore import QObject, pyqtSignal
@@ -227,6 +228,14 @@ class VMAFAnalyzer(QObject):
     def get_video_metadata(self, video_path, ffprobe_exe=None):
         try:
             from .yuvio import open_video
+            # one analysis asks four times for the same two files (app/vmaf_analyzer.py:320-321, :919-920): the answer is
+            # kept per (path, size, mtime) -- opening a clip maps it and finds its frames
+            st = os.stat(video_path)
+            key = (os.path.abspath(video_path), st.st_size, st.st_mtime_ns)
+            hit = _METADATA_CACHE.get(key)
+            if hit is not None:
+                logger.info(f"Video metadata extracted: {hit['width']}x{hit['height']} @ {hit['frame_rate']}fps")
+                return dict(hit, path=video_path)
             info = open_video(video_path).info
             fps = info.fps
             md = {
@@ -241,6 +250,9 @@ class VMAFAnalyzer(QObject):
                 "nb_frames": info.n_frames,
             }
             logger.info(f"Video metadata extracted: {md['width']}x{md['height']} @ {md['frame_rate']}fps")
+            if len(_METADATA_CACHE) > 64:
+                _METADATA_CACHE.clear()
+            _METADATA_CACHE[key] = dict(md)
             return md
         except Exception as e:
             logger.error(f"Error extracting video metadata: {e}")

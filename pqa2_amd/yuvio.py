@@ -117,6 +117,13 @@ class Y4MReader:
         size = self._mm.shape[0]
         self._offsets = []
         off = self._data_off
+        # the common case -- every frame header is the bare 6-byte "FRAME\n" -- is recognised from the first, the middle
+        # and the last header of the frame count the file size implies: three page touches instead of one per frame
+        n_plain = (size - off) // (fb + 6)
+        if n_plain > 0 and all(bytes(self._mm[off + k * (fb + 6):off + k * (fb + 6) + 6]) == b"FRAME\n"
+                               for k in {0, n_plain // 2, n_plain - 1}):
+            self._offsets = [off + k * (fb + 6) + 6 for k in range(n_plain)]
+            off = size   # nothing left to scan
         while off + 6 <= size:
             if bytes(self._mm[off:off + 5]) != b"FRAME":
                 break

@@ -336,3 +336,46 @@ def test_a_run_of_frames_from_files_in_one_call_matches_frame_by_frame(tmp_path)
             finally:
                 os.environ.pop("PQA_FD_RUN")
             assert np.array_equal(res["records"].view(np.uint64), res1["records"].view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_a_parked_context_is_reused_and_scores_the_same(tmp_path):
+    """pipeline.score_files() parks its context (FeatureEngine.release) and the next analysis of the same configuration takes
+    it back through pqa_reset instead of creating one: same records bit for bit, whatever ran in between -- a different clip
+    of the same geometry (motion continuity must not leak: the first frame's motion is 0 again), a bookend pass that switched
+    the gray mode, a different geometry (the parked context is replaced, never two), PQA_CONTEXT_CACHE=0 (nothing parked)."""
+    import os
+    from pqa2_amd import _native as N
+    from pqa2_amd import engine as E
+    from pqa2_amd import pipeline, synth, yuvio
+    E.clear_parked()
+
+    def clip(tag, w, h, n, seed):
+        refs, diss = synth.make_clip(w, h, n, 8, chroma=True)
+        info = synth.clip_info(w, h, 8)
+        rp, dp = str(tmp_path / f"r_{tag}.y4m"), str(tmp_path / f"d_{tag}.y4m")
+        yuvio.write_y4m(rp, refs if seed == 0 else refs[::-1], info)
+        yuvio.write_y4m(dp, diss if seed == 0 else diss[::-1], info)
+        return rp, dp
+
+    a = clip("a", 320, 180, 9, 0)
+    b = clip("b", 320, 180, 9, 1)      # same geometry, other content (the frames in reverse order)
+    c = clip("c", 256, 144, 5, 0)
+    first = pipeline.score_files(*a, "vmaf_v0.6.1")["records"]
+    assert len(E._PARKED) == 1
+    other = pipeline.score_files(*b, "vmaf_v0.6.1")["records"]
+    assert len(E._PARKED) == 1 and other[0, N.REC_MOTION] == 0.0 and not np.array_equal(other, first)
+    again = pipeline.score_files(*a, "vmaf_v0.6.1")["records"]
+    assert np.array_equal(first.view(np.uint64), again.view(np.uint64))
+    key_a = next(iter(E._PARKED))
+    pipeline.score_files(*c, "vmaf_v0.6.1")
+    assert len(E._PARKED) == 1 and next(iter(E._PARKED)) != key_a
+    os.environ["PQA_CONTEXT_CACHE"] = "0"
+    try:
+        E.clear_parked()
+        cold = pipeline.score_files(*a, "vmaf_v0.6.1")["records"]
+        assert len(E._PARKED) == 0
+    finally:
+        os.environ.pop("PQA_CONTEXT_CACHE")
+    assert np.array_equal(first.view(np.uint64), cold.view(np.uint64))
+    E.clear_parked()
