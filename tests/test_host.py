@@ -482,3 +482,66 @@ def test_worker_dies_when_reparented_to_a_subreaper_and_survives_a_live_parent(t
     assert f"worker signal {int(signal.SIGTERM)}" in r.stdout, (r.stdout, r.stderr[-500:])
     r = subprocess.run([sys.executable, "-c", _REAPER, root, "alive", str(tmp_path / "noted2")], capture_output=True, text=True, timeout=60, env=env)
     assert "worker rc 0 survived" in r.stdout, (r.stdout, r.stderr[-500:])
+
+
+# ---- round 4 host trims: the Y4M frame index, run strides, the metadata cache -------------------------------------------
+def test_y4m_frame_index_fast_path_equals_the_scan_and_falls_back_on_frame_parameters(tmp_path):
+    """A plain Y4M file (every frame header the bare "FRAME\\n") is indexed from three headers; a file whose FRAME headers
+    carry parameters of varying length must still be scanned header by header.  Same offsets as a byte-level scan either way,
+    and run_stride() -- what pqa_submit_fd_run is fed -- is only given where the frames really are equally spaced."""
+    w, h, n = 32, 18, 7
+    info = synth.clip_info(w, h, 8)
+    refs, _ = synth.make_clip(w, h, n, 8, chroma=True)
+    plain = str(tmp_path / "plain.y4m")
+    yuvio.write_y4m(plain, refs, info)
+    raw = open(plain, "rb").read()
+    head_end = raw.index(b"\n") + 1
+    fb = info.frame_bytes
+
+    def scan(buf):
+        offs, off = [], buf.index(b"\n") + 1
+        while off + 6 <= len(buf) and buf[off:off + 5] == b"FRAME":
+            start = buf.index(b"\n", off) + 1
+            if start + fb > len(buf):
+                break
+            offs.append(start)
+            off = start + fb
+        return offs
+
+    rd = yuvio.open_video(plain)
+    assert len(rd) == n and [rd.plane_offsets(i)[0] for i in range(n)] == scan(raw)
+    assert rd.run_stride(0, n) == fb + 6 and rd.run_stride(2, 1) == 0
+    # the same frames with a parameter on every other FRAME header (legal Y4M: "FRAME Ip\n")
+    odd = bytearray(raw[:head_end])
+    for i in range(n):
+        odd += (b"FRAME Ip\n" if i % 2 else b"FRAME\n") + raw[scan(raw)[i]:scan(raw)[i] + fb]
+    path = str(tmp_path / "params.y4m")
+    open(path, "wb").write(bytes(odd))
+    rd2 = yuvio.open_video(path)
+    assert len(rd2) == n and [rd2.plane_offsets(i)[0] for i in range(n)] == scan(bytes(odd))
+    assert rd2.run_stride(0, 3) is None and rd2.run_stride(0, 1) == 0
+    for i in range(n):
+        assert np.array_equal(np.asarray(rd2.frame(i)[0]), refs[i][0])
+    # a truncated plain file: the last, incomplete frame is not counted (fast path and scan agree)
+    cut = str(tmp_path / "cut.y4m")
+    open(cut, "wb").write(raw[:scan(raw)[n - 1] + fb // 2])
+    assert len(yuvio.open_video(cut)) == n - 1
+
+
+def test_metadata_cache_follows_the_file(tmp_path):
+    """get_video_metadata keeps its answer per (path, size, mtime): a rewritten file must be looked at again."""
+    import os
+    import time
+    from pqa2_amd.vmaf_analyzer import VMAFAnalyzer
+    an = VMAFAnalyzer()
+    p = str(tmp_path / "clip.y4m")
+    refs, _ = synth.make_clip(32, 18, 5, 8, chroma=True)
+    yuvio.write_y4m(p, refs, synth.clip_info(32, 18, 8))
+    a = an.get_video_metadata(p)
+    assert a["nb_frames"] == 5 and an.get_video_metadata(p) == a
+    refs2, _ = synth.make_clip(48, 26, 3, 8, chroma=True)
+    yuvio.write_y4m(p, refs2, synth.clip_info(48, 26, 8))
+    os.utime(p, ns=(time.time_ns(), time.time_ns() + 5_000_000_000))
+    b = an.get_video_metadata(p)
+    assert (b["width"], b["height"], b["nb_frames"]) == (48, 26, 3)
+    assert an.get_video_metadata(str(tmp_path / "missing.y4m")) is None
