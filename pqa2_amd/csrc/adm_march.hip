@@ -261,8 +261,13 @@ template <typename T>
 __global__ __launch_bounds__(kBlock, PQA_ADM_MARCH_OCC) void adm_march_kernel(const AdmMarchArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n_seg = a.seg_first[3];
-  const int id = xcd_remap(blockIdx.x, a.n_sg * n_seg);
+  // NOT xcd_remap (see adm_pyramid.hip): segments outside the crop window cost a third of those inside, and a contiguous
+  // range of ids per XCD hands some XCDs only the cheap ones
+#ifdef PQA_ADM_XCD_REMAP
+  const int id = xcd_remap(blockIdx.x, a.n_sg * a.seg_first[3]);
+#else
+  const int id = blockIdx.x;
+#endif
   const int sg = id % a.n_sg, seg = id / a.n_sg;
   const int stripe = sg * 4 + wave;
   const int fr = blockIdx.y;

@@ -291,7 +291,14 @@ __global__ __launch_bounds__(kBlock, PQA_ADM_PYRAMID_OCC) void adm_pyramid_kerne
   __shared__ double dsum[12][kBlock];   // per-thread double sums: scale 0 (6), scale 1 (6); no thread reads another's
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // NOT xcd_remap: that gives every XCD one contiguous range of ids -- the same rows of every frame -- and the rows differ 3 x in
+  // cost (inside / outside the crop window): the XCDs that drew the middle of the frame worked while the others idled.
+  // Consecutive ids go to the XCDs round-robin, which deals every XCD the same mix.
+#ifdef PQA_ADM_XCD_REMAP
   const int id = xcd_remap(blockIdx.x, a.n_sg * a.n_seg);
+#else
+  const int id = blockIdx.x;
+#endif
   const int sg = id % a.n_sg, seg = id / a.n_sg;
   const int stripe = sg * 4 + wave;
   const int fr = blockIdx.y;
