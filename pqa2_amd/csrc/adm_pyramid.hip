@@ -45,6 +45,7 @@ struct PyramidArgs {
   int w, h, ow0, oh0, ow1, oh1;
   int aligned;                             // rows allow one four-sample load per lane
   int n_stripes, n_sg, seg_rows, n_seg;    // seg_rows: scale-1 rows per segment
+  int n_frames;
   int left0, top0, right0, bottom0, left1, top1, right1, bottom1;
   float inv_scale;
   Consts k0, k1;
@@ -291,17 +292,22 @@ __global__ __launch_bounds__(kBlock, PQA_ADM_PYRAMID_OCC) void adm_pyramid_kerne
   __shared__ double dsum[12][kBlock];   // per-thread double sums: scale 0 (6), scale 1 (6); no thread reads another's
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // NOT xcd_remap: that gives every XCD one contiguous range of ids -- the same rows of every frame -- and the rows differ 3 x in
-  // cost (inside / outside the crop window): the XCDs that drew the middle of the frame worked while the others idled.
-  // Consecutive ids go to the XCDs round-robin, which deals every XCD the same mix.
-#ifdef PQA_ADM_XCD_REMAP
-  const int id = xcd_remap(blockIdx.x, a.n_sg * a.n_seg);
+  // Which (frame, segment, stripe group) a workgroup takes.  NOT xcd_remap: that gives every XCD one contiguous range of ids
+  // -- the same rows of every frame -- and the rows differ 3 x in cost (inside / outside the crop window): the XCDs that
+  // drew the middle of the frame worked while the others idled.  Consecutive ids go to the XCDs round-robin, which deals
+  // every XCD the same mix.  And the ORDER is longest-first: a wave lives ~75 us and a launch is under three rounds of
+  // them, so whatever is dispatched last decides the tail -- the segments in the middle of the frame (full chain) of ALL
+  // frames go first, those at its top and bottom (approximation band only, a third of the cost) last.
+#ifdef PQA_ADM_PYRAMID_PLAIN_ORDER
+  const int sg = blockIdx.x % a.n_sg, seg = (blockIdx.x / a.n_sg) % a.n_seg, fr = blockIdx.x / (a.n_sg * a.n_seg);
 #else
-  const int id = blockIdx.x;
+  const int sg = blockIdx.x % a.n_sg;
+  const int t = blockIdx.x / a.n_sg;
+  const int fr = t % a.n_frames, k = t / a.n_frames;                         // k: rank of the segment, centre-out
+  const int seg = (a.n_seg - 1) / 2 + ((k & 1) ? (k + 1) / 2 : -(k / 2));
 #endif
-  const int sg = id % a.n_sg, seg = id / a.n_sg;
+  const int id = seg * a.n_sg + sg;
   const int stripe = sg * 4 + wave;
-  const int fr = blockIdx.y;
   double* __restrict__ part0 = a.part0 + ((int64_t)fr * a.n_part + (int64_t)id * 4 + wave) * 6;
   double* __restrict__ part1 = a.part1 + ((int64_t)fr * a.n_part + (int64_t)id * 4 + wave) * 6;
   if (stripe >= a.n_stripes) {   // idle wave of the last group
@@ -383,7 +389,8 @@ bool launch_adm_pyramid(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun di
   a.part0 = partials0; a.part1 = partials1;
   a.n_part = a.n_sg * 4 * a.n_seg;
   if (n_partials) *n_partials = a.n_part;
-  const dim3 grid(a.n_sg * a.n_seg, n_frames), block(kBlock);
+  a.n_frames = n_frames;
+  const dim3 grid((unsigned)a.n_sg * a.n_seg * n_frames), block(kBlock);
   if (elem == ELEM_U16) hipLaunchKernelGGL((adm_pyramid_kernel<uint16_t>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((adm_pyramid_kernel<uint8_t>), grid, block, 0, stream, a);
   *err = hipGetLastError();
