@@ -46,6 +46,7 @@ struct AdmMarchArgs {
   int w, h, ow, oh;
   int aligned;                             // rows allow one two-sample load per lane
   int n_stripes, n_sg;                     // stripes, groups of four stripes (one workgroup each)
+  int n_frames;
   int left, top, right, bottom;            // accumulation window in band coordinates
   int reg_start[4];                        // row regions [0, top), [top, bottom), [bottom, oh): starts, reg_start[3] = oh
   int seg_rows[3], seg_first[4];           // rows per segment of a region; first segment id of a region, seg_first[3] = total
@@ -261,16 +262,17 @@ template <typename T>
 __global__ __launch_bounds__(kBlock, PQA_ADM_MARCH_OCC) void adm_march_kernel(const AdmMarchArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // NOT xcd_remap (see adm_pyramid.hip): segments outside the crop window cost a third of those inside, and a contiguous
-  // range of ids per XCD hands some XCDs only the cheap ones
-#ifdef PQA_ADM_XCD_REMAP
-  const int id = xcd_remap(blockIdx.x, a.n_sg * a.seg_first[3]);
-#else
-  const int id = blockIdx.x;
-#endif
-  const int sg = id % a.n_sg, seg = id / a.n_sg;
+  // Which (frame, segment, stripe group) a workgroup takes: ids as they come (NOT xcd_remap: a contiguous range of ids per
+  // XCD is the same rows of every frame, and segments outside the crop window cost a third of those inside) and
+  // longest-first -- the segments inside the window of ALL frames, then the approximation-band-only regions below and above
+  // (adm_pyramid.hip has the measurements).
+  const int n_seg = a.seg_first[3];
+  const int sg = blockIdx.x % a.n_sg;
+  const int t = blockIdx.x / a.n_sg;
+  const int fr = t % a.n_frames, k = t / a.n_frames;
+  const int seg = (k + a.seg_first[1]) % n_seg;        // region 1 first, then region 2, then region 0
+  const int id = seg * a.n_sg + sg;
   const int stripe = sg * 4 + wave;
-  const int fr = blockIdx.y;
   double* __restrict__ part = a.partials + ((int64_t)fr * a.n_part + (int64_t)id * 4 + wave) * 6;
   const int region = seg >= a.seg_first[2] ? 2 : seg >= a.seg_first[1] ? 1 : 0;
   const int r0 = a.reg_start[region] + (seg - a.seg_first[region]) * a.seg_rows[region];
@@ -394,7 +396,8 @@ bool launch_adm_march(hipStream_t stream, int scale, Elem elem, PlaneRun ref, Pl
   a.partials = partials;
   a.n_part = a.n_sg * 4 * p.seg_first[3];
   if (n_partials) *n_partials = a.n_part;
-  const dim3 grid(a.n_sg * p.seg_first[3], n_frames), block(kBlock);
+  a.n_frames = n_frames;
+  const dim3 grid((unsigned)a.n_sg * p.seg_first[3] * n_frames), block(kBlock);
   switch (elem) {
     case ELEM_U8: hipLaunchKernelGGL((adm_march_kernel<uint8_t>), grid, block, 0, stream, a); break;
     case ELEM_U16: hipLaunchKernelGGL((adm_march_kernel<uint16_t>), grid, block, 0, stream, a); break;
