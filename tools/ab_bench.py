@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of two builds of libpqa_vmaf.so in ONE process on ONE device
 (cdna_hip_programming.md rule 24: perf deltas come from interleaved rounds in one process; boxes differ by
-several percent).  usage: ab_bench.py A.so B.so [--size 3840x2160] [--frames 96] [--rounds 7]"""
+several percent).  usage: ab_bench.py A.so B.so [--size 3840x2160] [--frames 96] [--rounds 7]
+A library may carry environment switches that pqa_create reads once: path/to/lib.so@PQA_MULTI_STREAM=3,PQA_X=1 (set around
+that library's pqa_create only), so two modes of ONE build can be timed against each other."""
 import argparse, ctypes as C, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +24,19 @@ clip = synth_torch.make_clip_cuda(w, h, a.frames, a.bits)
 R, D = clip["ref"][0], clip["dis"][0]
 torch.cuda.synchronize()
 
-def bind(path):
+def bind(spec):
+    path, _, envs = spec.partition("@")
+    kv = dict(e.split("=", 1) for e in envs.split(",") if e)
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update(kv)
+    try:
+        return _bind(path)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+def _bind(path):
     lib = C.CDLL(os.path.abspath(path))
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.pqa_config_init.argtypes = [C.POINTER(N.PqaConfig), C.c_uint32, C.c_uint32]; lib.pqa_config_init.restype = None
@@ -53,4 +67,4 @@ for rnd in range(a.rounds + 1):
         if rnd:
             times[i].append(dt)
 for p, t in zip(a.libs, times):
-    print(f"{os.path.basename(p):28s} median {a.frames / statistics.median(t):9.1f} fps   best {a.frames / min(t):9.1f} fps   ({len(t)} rounds)")
+    print(f"{os.path.basename(p.partition('@')[0]) + ('@' + p.partition('@')[2] if '@' in p else ''):44s} median {a.frames / statistics.median(t):9.1f} fps   best {a.frames / min(t):9.1f} fps   ({len(t)} rounds)")

@@ -17,7 +17,21 @@ CASES = [(3840, 2160, 8, 6), (1920, 1080, 8, 6), (1039, 913, 8, 4), (200, 120, 8
          (1280, 720, 10, 4), (720, 486, 12, 3)]
 
 
-def run(path, w, h, bits, n, R, D):
+def run(spec, w, h, bits, n, R, D):
+    # lib.so@PQA_X=1,PQA_Y=2: switches pqa_create reads once, set around this library's context only
+    path, _, envs = spec.partition("@")
+    kv = dict(e.split("=", 1) for e in envs.split(",") if e)
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update(kv)
+    try:
+        return _run(path, w, h, bits, n, R, D)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+def _run(path, w, h, bits, n, R, D):
     lib = C.CDLL(os.path.abspath(path))
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.pqa_config_init.argtypes = [C.POINTER(N.PqaConfig), C.c_uint32, C.c_uint32]; lib.pqa_config_init.restype = None
