@@ -137,6 +137,9 @@ def main():
     result = {}
     _stage(f"context created (batch {args.batch})")
 
+    n_launch = -(-F // args.batch)
+    per_launch = -(-F // n_launch)
+
     def step():
         eng.reset()
         eng.submit_resident(a, F, ref_ptrs, dis_ptrs, row_pitch, frame_pitch, halo_ptr, row_pitch[0])
@@ -146,8 +149,8 @@ def main():
         rec = np.empty((F, N.RECORD_DOUBLES))
         vm_local = np.empty(F)
         scored = 0
-        for b0 in range(0, F, args.batch):
-            n = min(args.batch, F - b0)
+        for b0 in range(0, F, per_launch):   # the library cuts a run into equal launches (pqa_submit_device)
+            n = min(per_launch, F - b0)
             rec[b0:b0 + n] = eng.collect(a + b0, n)
             if world == 1:
                 e = b0 + n
@@ -220,7 +223,7 @@ def main():
             "config": {"workload": f"{args.workload} {w}x{h} {bpc}-bit, {model_name}, {F} frames/GPU"
                                    f"{' + PSNR/SSIM all planes' if side else ''}"
                                    f"{f' [--fixed-point {args.fixed_point}: libvmaf integer arithmetic]' if args.fixed_point else ''}",
-                       "frames_per_gpu": F, "frames_total": total, "batch": args.batch,
+                       "frames_per_gpu": F, "frames_total": total, "batch": args.batch, "frames_per_launch": per_launch,
                        "parallelism": f"frame-shard x{world}, 1-frame motion halo, all-gather of records + of scores"},
             "pooled_vmaf_mean": round(result["pooled"]["mean"], 6),
         }

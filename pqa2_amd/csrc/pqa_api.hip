@@ -1100,9 +1100,13 @@ int pqa_submit_device(pqa_ctx* c, int64_t first_index, int32_t n_frames, const p
   int rc = flush_pending(c);
   if (rc != PQA_OK) return rc;
   if ((rc = check_slots_free(c, first_index, n_frames)) != PQA_OK) return rc;   // the whole run, before any batch is launched
+  // a run longer than a batch goes down in EQUAL launches (300 frames at batch 32: ten of 30, not nine of 32 and one of 12 --
+  // a short launch pays the same ramp and tail for fewer waves); records do not depend on how a run is cut
+  const int n_launch = (n_frames + c->B - 1) / c->B;
+  const int per = n_launch ? (n_frames + n_launch - 1) / n_launch : 0;
   for (int done = 0; done < n_frames;) {
     if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
-    const int n = n_frames - done < c->B ? n_frames - done : c->B;
+    const int n = n_frames - done < per ? n_frames - done : per;
     pqa_device_clip r = *ref, d = *dis;
     for (int p = 0; p < c->n_planes; ++p) {
       r.plane[p] = (const uint8_t*)ref->plane[p] + (int64_t)done * ref->frame_pitch[p];
