@@ -104,8 +104,8 @@ def main():
             dist.init_process_group("gloo")
 
     w, h, bpc, model_name, side = WORKLOADS[args.workload]
-    if args.batch <= 0:   # same rule as pqa_create: about 512 MiB of luma per launch, 8..256 frames
-        args.batch = int(max(8, min(256, (512 << 20) // (2 * w * h * (1 if bpc <= 8 else 2)))))
+    if args.batch <= 0:   # same rule as pqa_create: about 1.5 GiB of luma per launch, 8..256 frames
+        args.batch = int(max(8, min(256, (1536 << 20) // (2 * w * h * (1 if bpc <= 8 else 2)))))
     F = args.frames
     total = F * world
     a = rank * F

@@ -79,7 +79,7 @@ typedef struct pqa_config {
   uint32_t chroma_hshift;      /* log2 horizontal chroma subsampling (4:2:0 -> 1)                 */
   uint32_t chroma_vshift;      /* log2 vertical chroma subsampling   (4:2:0 -> 1)                 */
   uint32_t features;           /* PQA_FEAT_* mask                                                 */
-  uint32_t max_batch;          /* frames per kernel launch (0 -> auto: ~512 MiB of luma, 8..256)    */
+  uint32_t max_batch;          /* frames per kernel launch (0 -> auto: ~1.5 GiB of luma, 8..256)   */
   uint32_t result_capacity;    /* records kept on the device, ring indexed by frame_index
                                   (0 -> default 16384)                                            */
   uint32_t n_subsample;        /* libvmaf n_subsample (:379): VIF/ADM on frames i % k == 0 only;

@@ -135,7 +135,8 @@ __device__ __forceinline__ double march(const MotionMarchArgs& a, const PairLoad
 }
 
 #ifndef PQA_MOTION_SEG_ROWS
-#define PQA_MOTION_SEG_ROWS 64   /* multiple of 4; a segment feeds 4 rows more than it owns */
+#define PQA_MOTION_SEG_ROWS 128  /* multiple of 4; a segment feeds 4 rows more than it owns.  64 while the automatic batch was 32
+                                    frames; at 97 frames per launch 128 rows: +4.8 % on the motion chain (profiles/r06i_launch_shapes_ab.txt) */
 #endif
 
 template <typename T>

@@ -865,9 +865,11 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
   c->device = cfg->device;
   if (cfg->max_batch) {
     c->B = (int)cfg->max_batch;
-  } else {  // auto: about 512 MiB of luma per launch (2160p -> 32, 1080p -> 128), enough tiles to fill 256 CUs
+  } else {  // auto: about 1.5 GiB of luma per launch (2160p -> 97, 1080p -> 256): every launch pays a ramp and a tail, and the
+            // deep scales are rounds of few, long-lived waves -- 32 -> 96 frames per launch measured +3 % at 2160p
+            // (profiles/r06h_batch.txt); the workspace that goes with it is 43.5 MB per 2160p frame, 4.2 GB of the 288
     const int64_t per_frame = 2ll * cfg->width * cfg->height * (cfg->bit_depth > 8 ? 2 : 1);
-    c->B = (int)((512ll << 20) / per_frame);
+    c->B = (int)((1536ll << 20) / per_frame);
     if (c->B < 8) c->B = 8;
   }
   if (c->B > 256) c->B = 256;

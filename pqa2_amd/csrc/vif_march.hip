@@ -611,7 +611,9 @@ bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun d
   // must not depend on how many frames share the launch.
   int seg = a.row_blocks;
 #ifndef PQA_MARCH_WAVES_PER_FRAME
-#define PQA_MARCH_WAVES_PER_FRAME 1536   /* x 32 frames = 49 152 waves: swept 6 144 .. 98 304 per launch on the box */
+#define PQA_MARCH_WAVES_PER_FRAME 768    /* at 2160p; x 97 frames (the automatic batch) = 74 496 waves per launch.  1 536 while the batch
+                                            was 32 (swept 6 144 .. 98 304 waves per launch); with 97 frames per launch 34-block segments beat
+                                            17-block ones by 2.3 % on the VIF chain (profiles/r06i_launch_shapes_ab.txt) */
 #endif
 #ifndef PQA_MARCH_WAVES_SCALED
 #define PQA_MARCH_WAVES_SCALED 1
