@@ -149,25 +149,28 @@ def main():
         rec = np.empty((F, N.RECORD_DOUBLES))
         vm_local = np.empty(F)
         scored = 0
+        clip_end = a + F == total            # this rank holds the clip's last frame (its motion2 is its own motion)
         for b0 in range(0, F, per_launch):   # the library cuts a run into equal launches (pqa_submit_device)
             n = min(per_launch, F - b0)
             rec[b0:b0 + n] = eng.collect(a + b0, n)
-            if world == 1:
-                e = b0 + n
-                upto = e if e == F else e - 1
-                if upto > scored:
-                    m = M.metrics_from_records(rec[scored:e], w, h, prefix)
-                    vm_local[scored:upto] = M.score_frames(model, {k: v[:upto - scored] for k, v in m.items()})["vmaf"]
-                    scored = upto
+            e = b0 + n
+            upto = e if (e == F and clip_end) else e - 1
+            if upto > scored:
+                m = M.metrics_from_records(rec[scored:e], w, h, prefix)
+                vm_local[scored:upto] = M.score_frames(model, {k: v[:upto - scored] for k, v in m.items()})["vmaf"]
+                scored = upto
         if world == 1:
             full, vmaf = rec, vm_local
         else:
+            # every rank has scored its own frames batch by batch, under its own kernels, exactly as at N = 1; what is left
+            # is the LAST frame of its chunk, whose motion2 needs the first motion of the next rank's chunk: one all-gather
+            # of the records (192 B per frame; rank 0 reports them), one frame through the SVM, and a second 8-byte-per-frame
+            # gather of the scores.  No serial host stage grows with N.
             full = shard.gather_records(rec, total, world, rank, gather_dev)
-            # every rank now holds all records (motion2 needs the neighbour's motion); it runs the SVM for its own
-            # frames only and a second 8-byte-per-frame gather collects the scores: no serial host stage at N = 8
-            metrics = M.metrics_from_records(full, w, h, prefix)
-            mine = {k: v[a:a + F] for k, v in metrics.items()}
-            vmaf = shard.gather_vector(M.score_frames(model, mine)["vmaf"], total, world, rank, gather_dev)
+            if scored < F:
+                m = M.metrics_from_records(full[a + scored:a + F + 1], w, h, prefix)
+                vm_local[scored:F] = M.score_frames(model, {k: v[:F - scored] for k, v in m.items()})["vmaf"]
+            vmaf = shard.gather_vector(vm_local, total, world, rank, gather_dev)
         if rank == 0:
             result["records"] = full
             result["vmaf"] = vmaf

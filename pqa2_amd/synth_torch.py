@@ -39,6 +39,9 @@ def make_clip_cuda(w: int, h: int, n: int, bit_depth: int = 8, seed: int = 20250
     two_pi = 2 * math.pi
     for i in range(n):
         t = t0 + i
+        # the noise of frame t is a function of (seed, t) alone: a rank that generates frames a .. b of a sharded job gets the
+        # very frames the one-rank job has there (a generator that simply runs on would give every rank the noise of frames 0 ..)
+        gen.manual_seed(seed * 1000003 + 1 + t)
         s = (torch.sin(two_pi * (3.0 * u + 0.011 * t)) * torch.cos(two_pi * (2.0 * v - 0.007 * t))
              + 0.6 * torch.sin(two_pi * (7.0 * u + 5.0 * v + 0.017 * t))
              + 0.4 * torch.cos(two_pi * (13.0 * u - 11.0 * v - 0.013 * t)))
@@ -70,6 +73,7 @@ def make_clip_cuda(w: int, h: int, n: int, bit_depth: int = 8, seed: int = 20250
             cr = torch.empty((n, ch, cw), dtype=dtype, device=dev)
             cd = torch.empty((n, ch, cw), dtype=dtype, device=dev)
             for i in range(n):
+                gen.manual_seed(seed * 1000003 + (500000 if ph == 0.0 else 750000) + t0 + i)
                 c = 128.0 + 20.0 * torch.sin(two_pi * (1.5 * cx / cw + cy / ch + 0.005 * (t0 + i) + ph))
                 e = c + 1.5 * torch.randn((ch, cw), generator=gen, device=dev)
                 if bit_depth <= 8:

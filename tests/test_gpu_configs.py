@@ -346,6 +346,35 @@ def test_two_ranks_on_rccl_one_gpu_each_match_single_process(tmp_path):
         assert open(outs["one"][k]).read() == open(outs["two"][k]).read()
 
 
+def test_bench_ranks_sharing_the_gpu_score_the_clip_like_one_rank():
+    """bench.py's N > 1 step on the one-GPU box (gloo + --share-device; the driver's launch line otherwise): every rank scores
+    its own frames batch by batch under its kernels, the last frame of a chunk after the record gather (its motion2 needs the
+    next rank's first motion), the scores are gathered.  The pooled score of the 2 x 48- and 3 x 32-frame jobs must equal the
+    one-rank run over the same 96-frame clip, and the line must say what the driver reads (n_gpus, weak, frames_total)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "2", "--warmup", "1", "--workload", "1080p", "--batch", "20", "--no-cpu-baseline", "--no-other-configs",
+              "--no-e2e"]
+    lines = {}
+    for ranks in (1, 2, 3):
+        launcher = [] if ranks == 1 else ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr",
+                                          "127.0.0.1", "--master-port", str(_free_port())]
+        cmd = [sys.executable] + launcher + [os.path.join(root, "bench.py"), "--gpus", str(ranks), "--frames", str(96 // ranks)] + common
+        if ranks > 1:
+            cmd += ["--backend", "gloo", "--share-device"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[ranks] = json.loads(r.stdout.strip().splitlines()[-1])
+    for ranks in (2, 3):
+        d = lines[ranks]
+        assert d["n_gpus"] == ranks and d["scaling"] == "weak" and d["config"]["frames_total"] == 96 and d["value"] > 0
+        assert d["pooled_vmaf_mean"] == lines[1]["pooled_vmaf_mean"], (ranks, d["pooled_vmaf_mean"], lines[1]["pooled_vmaf_mean"])
+
+
 @pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: arms itself on a multi-GPU box (the 1-GPU lease skips it)")
 def test_bench_two_gpus_on_rccl_prints_a_line():
     """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per GPU, RCCL): one JSON line

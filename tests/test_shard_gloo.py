@@ -83,3 +83,17 @@ def test_gather_vector_two_ranks(tmp_path):
     out = str(tmp_path / "v.npy")
     mp.spawn(_vec_worker, args=(2, port, out), nprocs=2, join=True)
     assert np.array_equal(np.load(out), np.arange(11) * 1.5)
+
+
+def test_synthetic_frames_do_not_depend_on_how_the_clip_is_sharded():
+    """bench.py gives every rank `make_clip_cuda(..., t0=first frame of its chunk)`: frame t must be the same bytes whichever
+    chunk generates it (luma and chroma, 8 and 10 bit), or an N-rank job scores a different clip than the one-rank job."""
+    import torch
+    from pqa2_amd import synth_torch
+    for bpc in (8, 10):
+        whole = synth_torch.make_clip_cuda(96, 64, 6, bpc, device="cpu", chroma=True)
+        part = synth_torch.make_clip_cuda(96, 64, 3, bpc, device="cpu", chroma=True, t0=3)
+        for side in ("ref", "dis"):
+            for p in range(3):
+                assert torch.equal(whole[side][p][3:], part[side][p]), (bpc, side, p)
+        assert not torch.equal(whole["dis"][0][0], whole["dis"][0][1])
