@@ -21,7 +21,8 @@ keep() { cp "$RAW/$1.err" "$OUT/logs/${TAG}_${WL}_$1.stderr.txt" 2>/dev/null || 
 # a pass that was KILLED at its time limit (124 / 137) ends the collection: no further GPU step after a timeout
 failed() { rc=$?; say "the $1 counter pass failed or timed out: its figures will be missing; last lines of its stderr (all of it: logs/${TAG}_${WL}_$1.stderr.txt):"; tail -n 8 "$RAW/$1.err" | cut -c1-300 | tee -a "$OUT/progress.log"; if [ "$rc" = 124 ] || [ "$rc" = 137 ]; then keep "$1"; say "pass $1 was killed at its time limit: stopping here"; exit 1; fi; }
 T="timeout -k 10 ${PQA_PROF_TIMEOUT:-75}"
-# 96 frames = three full launches of 32 (frames per launch is then exact); short, so a profiler stall costs little
+# 96 frames = one launch at 2160p (automatic batch 97), two of 48 at 2160p10 (frames per launch is then exact); three passes of
+# the clip (1 warm-up + 2 steps), short, so a profiler stall costs little
 FRAMES=96
 B="$R/bench.py --workload $WL --steps 2 --warmup 1 --frames $FRAMES --no-cpu-baseline --no-other-configs --no-e2e"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -- python3 $B > "$OUT/${TAG}_bench_${WL}_under_rocprof.json" 2> "$RAW/stats.err" || failed stats
