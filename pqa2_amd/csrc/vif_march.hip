@@ -403,8 +403,10 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
               f2{V[4][0], V[4][1]}, vrow && vcol[0], vrow && vcol[1], a.gain_limit);
     stat_pair(st, f2{V[0][2], V[0][3]}, f2{V[1][2], V[1][3]}, f2{V[2][2], V[2][3]}, f2{V[3][2], V[3][3]},
               f2{V[4][2], V[4][3]}, vrow && vcol[2], vrow && vcol[3], a.gain_limit);
-    const float num = (st.num2.x + st.num2.y) + ((fast_log2(st.pn.x) - fast_log2(st.qn.x)) + (fast_log2(st.pn.y) - fast_log2(st.qn.y)));
-    const float den = (st.den2.x + st.den2.y) + (fast_log2(st.pd.x) + fast_log2(st.pd.y));
+    // the log terms of the lane's four pixels as ONE log per product: in units U = 16 every factor lies in [1, 2^24) (narg <=
+    // sigma2_sq + sv_sq + sigma_nsq by Cauchy-Schwarz, each <= 2^22), four of them below 2^96 -- three v_log_f32 instead of six
+    const float num = (st.num2.x + st.num2.y) + (fast_log2(st.pn.x * st.pn.y) - fast_log2(st.qn.x * st.qn.y));
+    const float den = (st.den2.x + st.den2.y) + fast_log2(st.pd.x * st.pd.y);
     dnum += (double)num;
     dden += (double)den;
   };
