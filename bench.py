@@ -218,8 +218,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if not args.fixed_point else f"f32 + fixed-point extractors (mask {args.fixed_point})"), "data": "synthetic",
             "dtype_note": "every filter and statistic accumulates in f32.  VIF scale 0 (vif_march.hip) runs both passes on the f16 matrix "
-                          "cores: the HORIZONTAL pass multiplies exact integer digit planes by exact three-piece f16 taps (products "
-                          "exact in f32, f32 accumulators); the vertical pass feeds hi/lo f16 splits of those f32 results (about 22 "
+                          "cores: the HORIZONTAL pass multiplies exact integer digit planes by two-piece f16 taps (22 bits of each f32 "
+                          "tap; products exact in f32, f32 accumulators); the vertical pass feeds hi/lo f16 splits of those f32 results (about 22 "
                           "bits, the lo x lo term dropped) against two-piece taps, f32 accumulation -- an f32-grade evaluation in a "
                           "different rounding order, 8e-8 from f64 on the scale-0 numerator; fuzz bound of the whole path "
                           "|dVMAF| <= 0.0031 from 500 k pixels up (profiles/r03n_fuzz_summary.txt)",
@@ -261,18 +261,17 @@ def main():
                                "measured_limiter": "instruction issue: VALU (4 clk per wave64 instruction) + MFMA (8 issue clk of 16 each) on "
                                                    "one port per SIMD, 80 % busy at 3 waves per SIMD (profiles/*_sq_counters.txt); not HBM: see `valu`, `mfma`"}
             # matrix-core share of the same launches (v_mfma_f32_16x16x32_f16 = 16384 FLOP each; dense f16 peak 2.5 PFLOP/s,
-            # MI355X_MICROARCH.md).  March kernel: per 16 x 16 block 27 MFMAs in pass 1 (repeated once per segment) + 18 in
-            # pass 2; the segment rule is launch_vif_s0_march's (csrc/vif_march.hip)
-            mfma_wave_insts = 0
+            # MI355X_MICROARCH.md).  March kernel: per 16 x 16 block the pass-1 MFMAs (repeated once per segment) + 18 in
+            # pass 2; the counts and the segment rule are asked from the library (pqa_debug_vif_march_shape)
+            mfma_wave_insts, mfma_shape = 0, None
             if bpc <= 10 and not args.fixed_point:
-                n_cb, rbk = (w + 15) // 16, (h + 15) // 16
-                n_cbg = (n_cb + 3) // 4
-                seg = rbk
-                while seg > 8 and n_cbg * 4 * ((rbk + seg - 1) // seg) < 1536:
-                    seg = (seg + 1) // 2
-                seg = max(seg, min(rbk, 8))
-                n_seg = (rbk + seg - 1) // seg
-                mfma_wave_insts = n_cb * (27 * (rbk + n_seg) + 18 * rbk)
+                import ctypes as _C
+                shp = (_C.c_int32 * 6)()
+                if N.load().pqa_debug_vif_march_shape(w, h, _C.byref(shp)) == 0:   # the library's own segment rule and MFMA counts
+                    n_cb, rbk, seg, n_seg, m1, m2 = list(shp)
+                    mfma_shape = {"stripes": n_cb, "row_blocks": rbk, "blocks_per_segment": seg, "segments": n_seg,
+                                  "pass1_mfma_per_block": m1, "pass2_mfma_per_block": m2}
+                    mfma_wave_insts = n_cb * (m1 * (rbk + n_seg) + m2 * rbk)
             if cnt.get("valu_insts_per_wave"):
                 # issue floor = the clocks the VALU / matrix issue port of a SIMD is held per frame: SQ_INSTS_VALU counts the
                 # MFMAs too; an MFMA 16x16x32 holds the port 8 clocks (of the 16 it occupies the matrix pipe), every other
@@ -293,7 +292,9 @@ def main():
                     "source": cnt.get("valu_source")}
             if mfma_wave_insts:
                 mf = mfma_wave_insts * 16384.0
-                note = ("45 MFMAs per 16 x 16 output block (27 exact first-pass + 18 second-pass); a Toeplitz band uses 17 of "
+                note = (f"{mfma_shape['pass1_mfma_per_block'] + mfma_shape['pass2_mfma_per_block']} MFMAs per 16 x 16 output block "
+                        f"({mfma_shape['pass1_mfma_per_block']} first-pass + {mfma_shape['pass2_mfma_per_block']} second-pass; "
+                        f"{mfma_shape['blocks_per_segment']}-block segments repeat one first-pass block each); a Toeplitz band uses 17 of "
                         "the 32 K slots, so the USEFUL share of these FLOP is about half")
                 out["roofline"]["mfma"] = {"flop_per_frame": mf, "achieved_tflops": round(mf * frames_per_launch / (avg_ms * 1e-3) / 1e12, 1),
                                            "peak_tflops": 2500.0, "frac": round(mf * frames_per_launch / (avg_ms * 1e-3) / 2.5e15, 4),

@@ -263,6 +263,12 @@ PQA_API const char* pqa_profile_kernel_name(int kernel_id);
  * Returns the number of fragments, or -(halfwords needed) when `out` is too small. */
 PQA_API int pqa_debug_vif_march_table(uint16_t* out, int32_t capacity_halfwords);
 
+/* Test / measurement hook (no device needed): how the scale-0 VIF kernel cuts a width x height frame into waves, and what a
+ * 16 x 16 block costs on the matrix cores: out6 = {16-column stripes, 16-row blocks, blocks per segment, segments per stripe,
+ * first-pass MFMAs per block, second-pass MFMAs per block}.  A wave = one stripe x one segment; a segment repeats one block
+ * of the first pass.  bench.py prices `roofline.mfma` with it instead of mirroring the rule. */
+PQA_API int pqa_debug_vif_march_shape(uint32_t width, uint32_t height, int32_t* out6);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ EXPORTS = [
     "pqa_submit", "pqa_submit_fd", "pqa_submit_fd_run", "pqa_submit_device", "pqa_submit_surfaces", "pqa_set_motion_halo", "pqa_flush", "pqa_collect", "pqa_sync",
     "pqa_cancel", "pqa_reset", "pqa_last_error", "pqa_luma_stats_device", "pqa_luma_stats", "pqa_set_luma_gray",
     "pqa_profile_enable",
-    "pqa_profile_read", "pqa_profile_kernel_name", "pqa_debug_vif_march_table",
+    "pqa_profile_read", "pqa_profile_kernel_name", "pqa_debug_vif_march_table", "pqa_debug_vif_march_shape",
 ]
 
 
@@ -130,6 +130,7 @@ def load():
     lib.pqa_profile_enable.argtypes = [vp, C.c_int]
     lib.pqa_profile_read.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pqa_debug_vif_march_table.argtypes = [vp, i32]
+    lib.pqa_debug_vif_march_shape.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(i32 * 6)]
     lib.pqa_profile_kernel_name.argtypes = [C.c_int]
     lib.pqa_profile_kernel_name.restype = C.c_char_p
     assert lib.pqa_record_doubles() == RECORD_DOUBLES

@@ -53,6 +53,8 @@ int vif_march_partials_max(int w, int h);
 // host: the per-lane tap-matrix fragments the march kernel reads ([fragment][lane 0..63][8 f16 bit patterns]) -- no device
 // needed; returns the number of fragments, 0 when a tap does not split exactly, -(halfwords needed) when `out` is too small
 int vif_march_table(uint16_t* out, int capacity_halfwords);
+// {16-column stripes, 16-row blocks, blocks per segment, segments, pass-1 MFMAs per block, pass-2 MFMAs per block} of a w x h frame
+void vif_march_shape(int w, int h, int* out6);
 bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
                          int border101, double* partials, MutPlaneRun next_ref, MutPlaneRun next_dis, int* n_partials,
                          hipError_t* err);

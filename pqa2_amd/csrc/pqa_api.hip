@@ -1519,6 +1519,13 @@ int pqa_profile_read(pqa_ctx* c, int kernel_id, double* total_ms, uint64_t* laun
 }
 
 int pqa_debug_vif_march_table(uint16_t* out, int32_t capacity_halfwords) { return vif_march_table(out, capacity_halfwords); }
+int pqa_debug_vif_march_shape(uint32_t width, uint32_t height, int32_t* out6) {
+  if (!out6 || width == 0 || height == 0 || width > 65536 || height > 65536) return PQA_EINVAL;
+  int shape[6];
+  vif_march_shape((int)width, (int)height, shape);
+  for (int i = 0; i < 6; ++i) out6[i] = shape[i];
+  return PQA_OK;
+}
 
 const char* pqa_profile_kernel_name(int kernel_id) {
   return (kernel_id >= 0 && kernel_id < PQA_PROF_KERNELS) ? kProfNames[kernel_id] : "";

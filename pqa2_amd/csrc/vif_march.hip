@@ -9,7 +9,7 @@
 // 8-byte accumulator stores, two barriers per tile pair).  Here the second pass is an MFMA as well, and its operand comes
 // straight out of the first pass's accumulators:
 //
-//   pass 1 (exact):  D1[row][out col] = sum_k  X[row][in col k] * T1[k][out col]      X = integer digit planes (A operand)
+//   pass 1:          D1[row][out col] = sum_k  X[row][in col k] * T1[k][out col]      X = exact integer digit planes (A operand)
 //   pass 2:          D2[col][out row] = sum_k  P[col][in row k] * T2[k][out row]      P = D1 split into two f16 pieces
 //
 // v_mfma_f32_16x16x32_f16 keeps D[m][n] of lane l = (n = l & 15, m = 4 (l >> 4) + i): four ROWS of one column after pass 1.
@@ -23,9 +23,11 @@
 // 32-row window of the vertical filter is the pair (previous block, current block), so the only redundant work is the first
 // block of a segment ((L + 1) / L on pass 1 for a segment of L blocks).
 //
-// Pass 1 is exact exactly as in vif_s0_mfma_kernel: the five signals r', d', r'^2, d'^2, r'd' (r' = r - 128) enter as
-// base-256 digit planes whose 16-bit patterns are their own f16 encodings (k * 2^-24), every f32 tap is split into three
-// f16 pieces without loss, products are exact in f32 and the accumulator is f32.
+// Pass 1: the five signals r', d', r'^2, d'^2, r'd' (r' = r - 128) enter EXACTLY, as base-256 digit planes whose 16-bit
+// patterns are their own f16 encodings (k * 2^-24); every f32 tap enters as two f16 pieces = 22 bits of it (the third piece,
+// at most 2^-22 of the tap, was carried until round 4 -- 7 of 45 MFMAs per block for a difference of 4e-10 in the records,
+// three orders of magnitude inside the kernel's and the f32 oracle's own distance from f64: profiles/r06w_tap_pieces_ab.txt);
+// products are exact in f32 and the accumulator is f32.
 // Pass 2 splits each f32 result v into hi = f16(v), lo = f16(v - hi) (both round-to-nearest: |v - hi - lo| <= 2^-23 |v|, the
 // size of ONE f32 rounding) and each tap c * 2^8 into c1 = f16(.), c2 = f16(. - c1); it accumulates hi c1 + hi c2 + lo c1 in
 // f32 (the dropped lo c2 is below 2^-24 of the term).  That is an f32-grade evaluation in a different rounding order, not a
@@ -60,8 +62,8 @@ using namespace march;
 
 // fragments of the per-lane tap table (each: 64 lanes x 8 f16)
 enum : int {
-  F_HI = 0,    // 0..2   pass 1, c * 2^19 in three pieces (digits that weigh 2^8)
-  F_LO = 3,    // 3..5   pass 1, c * 2^11 in three pieces (means: all three; low digits: the first two)
+  F_HI = 0,    // 0..2   pass 1, c * 2^19 in pieces (digits that weigh 2^8); the kernel multiplies the first PQA_MARCH_TAP_PIECES
+  F_LO = 3,    // 3..5   pass 1, c * 2^11 in pieces (means and low digits)
   F_DR = 6,    // 6..8   pass 1, next scale's taps c' * 2^18, even output columns of REF in N slots 0..7
   F_DD = 9,    // 9..11  the same for DIS in N slots 8..15
   F_V = 12,    // 12,13  pass 2, c * 2^8 in two pieces, K order {previous block rows, current block rows}
@@ -141,6 +143,12 @@ __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2
 #ifndef PQA_MARCH_LDS_TABLES
 #define PQA_MARCH_LDS_TABLES 1
 #endif
+// PQA_MARCH_TAP_PIECES: f16 pieces per pass-1 tap on the means, the high digits and the next scale's input (the low digits
+// always took two): 2 = 22 bits of every f32 tap (38 MFMAs per block); 3 = the tap exactly (45; the test partner: VIF chain
+// -4.2 %, records 4e-10 apart)
+#ifndef PQA_MARCH_TAP_PIECES
+#define PQA_MARCH_TAP_PIECES 2
+#endif
 #ifndef PQA_MARCH_OCC
 #define PQA_MARCH_OCC (PQA_MARCH_LDS_TABLES ? 3 : 2)
 #endif
@@ -194,7 +202,8 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
 #pragma unroll
   for (int f = 0; f < kMarchFrags; ++f) {
     const bool in_lds = PQA_MARCH_LDS_TABLES && ((f >= F_DR && f < F_DR + 6) || (f >= F_VD && f < F_VD + 2) || (f >= F_WD && f < F_WD + 2));
-    const bool unused = W16 ? false : f >= F_L9;
+    const bool third = f == F_HI + 2 || f == F_LO + 2 || f == F_DR + 2 || f == F_DD + 2;
+    const bool unused = (W16 ? false : f >= F_L9) || (PQA_MARCH_TAP_PIECES < 3 && third);
     if (!in_lds && !unused) T[f] = __builtin_bit_cast(h8, a.tab[f * 64 + lane]);
   }
 #if PQA_MARCH_LDS_TABLES
@@ -287,13 +296,13 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
       const h8 A = frag4(ru[0], ru[1], ru[2], ru[3]);
       Dh[0] = mma(A, T[F_LO], z); Dd = mma(A, TD(F_DR), z);
       Dh[0] = mma(A, T[F_LO + 1], Dh[0]); Dd = mma(A, TD(F_DR + 1), Dd);
-      Dh[0] = mma(A, T[F_LO + 2], Dh[0]); Dd = mma(A, TD(F_DR + 2), Dd);
+      if (PQA_MARCH_TAP_PIECES == 3) { Dh[0] = mma(A, T[F_LO + 2], Dh[0]); Dd = mma(A, TD(F_DR + 2), Dd); }
     }
     {
       const h8 A = frag4(du[0], du[1], du[2], du[3]);
       Dh[1] = mma(A, T[F_LO], z); Dd = mma(A, TD(F_DD), Dd);
       Dh[1] = mma(A, T[F_LO + 1], Dh[1]); Dd = mma(A, TD(F_DD + 1), Dd);
-      Dh[1] = mma(A, T[F_LO + 2], Dh[1]); Dd = mma(A, TD(F_DD + 2), Dd);
+      if (PQA_MARCH_TAP_PIECES == 3) { Dh[1] = mma(A, T[F_LO + 2], Dh[1]); Dd = mma(A, TD(F_DD + 2), Dd); }
     }
 #pragma unroll
     for (int s = 2; s < 5; ++s) {   // r'^2, d'^2, r'd': exact integer products, split into two digits
@@ -335,14 +344,14 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
         const h8 A = frag4(t[0], t[1], t[2], t[3]);
         Dh[s] = mma(A, T[F_HI], Dh[s]);
         Dh[s] = mma(A, T[F_HI + 1], Dh[s]);
-        Dh[s] = mma(A, T[F_HI + 2], Dh[s]);
+        if (PQA_MARCH_TAP_PIECES == 3) Dh[s] = mma(A, T[F_HI + 2], Dh[s]);
       }
     }
     // pass 1 leaves every signal of an 8-bit clip times 2^-13 and the next scale's input times 2^-6 (operands k * 2^-24,
     // pieces of c * 2^11, c * 2^19 on the digits that weigh 2^8, c' * 2^18); for 10-bit clips the means again times 2^-13
     // and the squares times 2^-15 (base-1024 digits, low pieces c * 2^9), both still in sample units (x 4 and x 16).
     // Into pass 2: means as natural / 16, squares as natural, the next scale's input as natural.
-    // The means were filtered as samples: sum c (x - 128) = sum c x - 128 sum c, with sum c the exact sum of the f32 taps.
+    // The means were filtered as samples: sum c (x - 128) = sum c x - 128 sum c, with sum c the sum of the taps AS APPLIED (the pieces).
     constexpr float KM = W16 ? 128.0f : 512.0f, KS = W16 ? 2048.0f : 8192.0f, KD = W16 ? 16.0f : 64.0f;
     split4<H>(Dh[0], KM, a.mean_off, P.hi[0], P.lo[0]);
     split4<H>(Dh[1], KM, a.mean_off, P.hi[1], P.lo[1]);
@@ -523,6 +532,40 @@ int vif_march_table(uint16_t* out, int capacity_halfwords) {
   return build_table(out) ? kMarchFrags : 0;
 }
 
+// How a w x h frame is cut into waves (a function of the geometry only) and what a block costs on the matrix pipe:
+// out = {16-column stripes, 16-row blocks, blocks per segment, segments, pass-1 MFMAs per block, pass-2 MFMAs per block}.
+void vif_march_shape(int w, int h, int* out) {
+  int n_cb, n_cbg, row_blocks, seg_blocks, n_seg;
+  n_cb = (w + 15) / 16;
+  n_cbg = (n_cb + 3) / 4;
+  row_blocks = (h + 15) / 16;
+  // segment length: long enough that the repeated first block is cheap, short enough that a launch of a full batch has
+  // several waves per SIMD slot to balance.  A function of the GEOMETRY only: a frame's partial sums -- and so its record --
+  // must not depend on how many frames share the launch.
+  int seg = row_blocks;
+#ifndef PQA_MARCH_WAVES_PER_FRAME
+#define PQA_MARCH_WAVES_PER_FRAME 768    /* at 2160p; x 97 frames (the automatic batch) = 74 496 waves per launch.  1 536 while the batch
+                                            was 32 (swept 6 144 .. 98 304 waves per launch); with 97 frames per launch 34-block segments beat
+                                            17-block ones by 2.3 % on the VIF chain (profiles/r06i_launch_shapes_ab.txt) */
+#endif
+#ifndef PQA_MARCH_WAVES_SCALED
+#define PQA_MARCH_WAVES_SCALED 1
+#endif
+  // PQA_MARCH_WAVES_SCALED: the target follows the frame's pixel count (the automatic batch keeps the BYTES per launch
+  // constant, so a launch of smaller frames has as many waves with proportionally fewer per frame): 1080p marches
+  // segments of 17 blocks instead of 8 -- 18 / 17 instead of 9 / 8 on pass 1 -- VIF chain +7 %, whole path +4.9 % at 1080p,
+  // +3 % / +1 % at 720p (profiles/r06c_march_segments_ab.txt); 2160p and up are unchanged
+  const int want_waves = PQA_MARCH_WAVES_SCALED
+      ? (int)fmax(192.0, PQA_MARCH_WAVES_PER_FRAME * ((double)w * h) / (3840.0 * 2160.0)) : PQA_MARCH_WAVES_PER_FRAME;
+  while (seg > kMinSegBlocks && n_cbg * 4 * ((row_blocks + seg - 1) / seg) < want_waves) seg = (seg + 1) / 2;
+  if (seg < kMinSegBlocks) seg = row_blocks < kMinSegBlocks ? row_blocks : kMinSegBlocks;
+  seg_blocks = seg;
+  n_seg = (row_blocks + seg - 1) / seg;
+  out[0] = n_cb; out[1] = row_blocks; out[2] = seg_blocks; out[3] = n_seg;
+  out[4] = PQA_MARCH_TAP_PIECES == 3 ? 27 : 20;   // means 2 x P, low digits 3 x 2, high digits 3 x P, next scale's input 2 x P
+  out[5] = 18;
+}
+
 int vif_march_partials_max(int w, int h) {
   const int n_cbg = ((w + 15) / 16 + 3) / 4, row_blocks = (h + 15) / 16;
   return n_cbg * 4 * ((row_blocks + kMinSegBlocks - 1) / kMinSegBlocks);
@@ -536,7 +579,7 @@ hipError_t vif_march_prepare() {
   std::lock_guard<std::mutex> lock(g_tab_mu);
   if (g_tab[dev]) return hipSuccess;
   std::vector<uint16_t> h((size_t)kMarchFrags * 64 * 8);
-  if (!build_table(h.data())) return hipSuccess;   // a tap that does not split exactly: the older kernels stay in charge
+  if (!build_table(h.data()) && PQA_MARCH_TAP_PIECES == 3) return hipSuccess;   // a tap that does not split exactly: the older kernels stay in charge
   void* d = nullptr;
   if ((e = hipMalloc(&d, h.size() * 2)) != hipSuccess) return e;
   if ((e = hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) {
@@ -599,37 +642,23 @@ bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun d
     float c17[17], c9[9];
     gaussian(17, c17);
     gaussian(9, c9);
+    // the taps as pass 1 applies them: the sum of the pieces it multiplies (all of the f32 tap with three, 22 bits with two)
+    const auto applied = [](float c, double scale) {
+      uint16_t bits[3];
+      const double left = pieces((double)c * scale, PQA_MARCH_TAP_PIECES, bits, 1);
+      return ((double)c * scale - left) / scale;
+    };
     double s17 = 0.0, s9 = 0.0;
-    for (int k = 0; k < 17; ++k) s17 += (double)c17[k];
-    for (int k = 0; k < 9; ++k) s9 += (double)c9[k];
+    for (int k = 0; k < 17; ++k) s17 += applied(c17[k], 2048.0);
+    for (int k = 0; k < 9; ++k) s9 += applied(c9[k], 262144.0);
     a.mean_off = (float)(-128.0 * s17 / 16.0);
     a.dec_off = (float)(-128.0 * s9);
   }
-  a.n_cb = (w + 15) / 16;
-  a.n_cbg = (a.n_cb + 3) / 4;
-  a.row_blocks = (h + 15) / 16;
-  // segment length: long enough that the repeated first block is cheap, short enough that a launch of a full batch has
-  // several waves per SIMD slot to balance.  A function of the GEOMETRY only: a frame's partial sums -- and so its record --
-  // must not depend on how many frames share the launch.
-  int seg = a.row_blocks;
-#ifndef PQA_MARCH_WAVES_PER_FRAME
-#define PQA_MARCH_WAVES_PER_FRAME 768    /* at 2160p; x 97 frames (the automatic batch) = 74 496 waves per launch.  1 536 while the batch
-                                            was 32 (swept 6 144 .. 98 304 waves per launch); with 97 frames per launch 34-block segments beat
-                                            17-block ones by 2.3 % on the VIF chain (profiles/r06i_launch_shapes_ab.txt) */
-#endif
-#ifndef PQA_MARCH_WAVES_SCALED
-#define PQA_MARCH_WAVES_SCALED 1
-#endif
-  // PQA_MARCH_WAVES_SCALED: the target follows the frame's pixel count (the automatic batch keeps the BYTES per launch
-  // constant, so a launch of smaller frames has as many waves with proportionally fewer per frame): 1080p marches
-  // segments of 17 blocks instead of 8 -- 18 / 17 instead of 9 / 8 on pass 1 -- VIF chain +7 %, whole path +4.9 % at 1080p,
-  // +3 % / +1 % at 720p (profiles/r06c_march_segments_ab.txt); 2160p and up are unchanged
-  const int want_waves = PQA_MARCH_WAVES_SCALED
-      ? (int)fmax(192.0, PQA_MARCH_WAVES_PER_FRAME * ((double)w * h) / (3840.0 * 2160.0)) : PQA_MARCH_WAVES_PER_FRAME;
-  while (seg > kMinSegBlocks && a.n_cbg * 4 * ((a.row_blocks + seg - 1) / seg) < want_waves) seg = (seg + 1) / 2;
-  if (seg < kMinSegBlocks) seg = a.row_blocks < kMinSegBlocks ? a.row_blocks : kMinSegBlocks;
-  a.seg_blocks = seg;
-  a.n_seg = (a.row_blocks + seg - 1) / seg;
+  {
+    int shape[6];
+    vif_march_shape(w, h, shape);
+    a.n_cb = shape[0]; a.n_cbg = (a.n_cb + 3) / 4; a.row_blocks = shape[1]; a.seg_blocks = shape[2]; a.n_seg = shape[3];
+  }
   a.n_part = a.n_cbg * 4 * a.n_seg;
   if (n_partials) *n_partials = a.n_part;
   if (elem == ELEM_U16) hipLaunchKernelGGL(vif_s0_march_kernel<uint16_t>, dim3(a.n_cbg * a.n_seg, n_frames), dim3(kBlock), 0, stream, a);

@@ -383,8 +383,9 @@ def test_march_tap_tables_replayed_in_numpy_are_the_separable_gaussian():
     its operand straight from the first pass's accumulator registers, which only works because the K order of its tap matrix
     is DEFINED by that register layout.  Replay the whole dataflow on the CPU with the very table the kernel loads
     (pqa_debug_vif_march_table) -- operand and accumulator lane layouts of v_mfma_f32_16x16x32_f16 spelled out -- and compare
-    with a direct convolution: both passes, both block orders (F_V / F_W), the pieces that must sum to the f32 taps exactly
-    (pass 1) or to 22 bits (pass 2), and the next scale's 9-tap even-row / even-column planes for ref and dis."""
+    with a direct convolution: both passes, both block orders (F_V / F_W), the pieces -- all three of a pass-1 tap sum to the
+    f32 tap exactly, the two the kernel multiplies (PQA_MARCH_TAP_PIECES = 2 since round 4) and the two of a pass-2 tap to 22
+    bits of it -- and the next scale's 9-tap even-row / even-column planes for ref and dis."""
     T = _march_table()
     F_HI, F_LO, F_DR, F_DD, F_V, F_VD, F_W, F_WD, F_L9 = 0, 3, 6, 9, 12, 14, 16, 18, 20
     c17, c9 = _gauss(17), _gauss(9)
@@ -398,9 +399,17 @@ def test_march_tap_tables_replayed_in_numpy_are_the_separable_gaussian():
     l9 = sum(_as_B(T[F_L9 + p]) for p in range(2))                     # c * 2^9, two pieces (22 bits of the tap)
     assert np.array_equal(X @ lo, want * 2048.0) and np.array_equal(X @ hi, want * 524288.0)
     assert np.abs(X @ l9 / 512.0 - want).max() < 2e-6 * np.abs(want).max()
+    # what the kernel multiplies: the first two pieces -- the SAME 22 bits of the tap in both tables (pieces scale with the
+    # power of two), a filter whose taps differ from the f32 ones by less than 2^-22 each
+    lo2 = sum(_as_B(T[F_LO + p]) for p in range(2))
+    hi2 = sum(_as_B(T[F_HI + p]) for p in range(2))
+    assert np.array_equal(hi2, lo2 * 256.0)
+    assert np.abs(lo2 - lo).max() <= 2.0 ** -22 * np.abs(lo).max() and np.abs(X @ lo2 / 2048.0 - want).max() < 3e-7 * np.abs(want).max()
     # next scale's input: slots 0..7 = even columns of the plane filtered through F_DR, 8..15 = of the one through F_DD
     dr = sum(_as_B(T[F_DR + p]) for p in range(3))
     dd = sum(_as_B(T[F_DD + p]) for p in range(3))
+    dr2, dd2 = sum(_as_B(T[F_DR + p]) for p in range(2)), sum(_as_B(T[F_DD + p]) for p in range(2))
+    assert np.abs(dr2 - dr).max() <= 2.0 ** -22 * np.abs(dr).max() and np.abs(dd2 - dd).max() <= 2.0 ** -22 * np.abs(dd).max()
     Y = rng.integers(0, 256, (16, 32)).astype(np.float64)
     got = X @ dr + Y @ dd
     for e in range(8):
