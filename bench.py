@@ -23,6 +23,10 @@ import os
 import sys
 import time
 
+# the pool's host driver supports dmabuf IPC only: without this RCCL (and any CUDA-tensor sharing across the ranks of an N > 1
+# job) fails with hipIpcGetMemHandle: invalid argument.  The boxes export it; a launcher that scrubs the environment must not matter.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

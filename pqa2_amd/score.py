@@ -51,6 +51,7 @@ def _die_with_parent(expected: int, getppid=os.getppid, kill=os.kill) -> None:
 
 def main(argv=None) -> int:
     parent = _expected_parent()    # before anything slow: imports, argument parsing
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool's driver: RCCL needs it (before torch loads)
     ap = argparse.ArgumentParser(prog="pqa2_amd.score")
     ap.add_argument("reference")
     ap.add_argument("distorted")
