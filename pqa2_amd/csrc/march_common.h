@@ -12,6 +12,7 @@ namespace march {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef short s2v __attribute__((ext_vector_type(2)));
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 

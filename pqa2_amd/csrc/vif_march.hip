@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
     // 16-bit lanes {col 2v, col 2v+1} of this lane's 8 columns.  8 bit: byte -> zero-extended half (one v_perm_b32 each);
     // 10 bit: the loaded dwords as they are.  r16 / d16: the same minus mid-grey, as signed 16-bit integers.
     constexpr short MID = W16 ? 512 : 128;
-    unsigned ru[4], du[4], r16[4], d16[4];
+    unsigned ru[4], du[4], r16[4], d16[4], r16s[4], d16s[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       if constexpr (W16) {
@@ -289,6 +289,10 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
       }
       r16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, ru[v]) - s2v{MID, MID});
       d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{MID, MID});
+      if constexpr (W16) {   // 64 (v - 512) in [-2^15, 2^15): the second factor of every product, see below
+        r16s[v] = __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, r16[v]) << s2v{6, 6}));
+        d16s[v] = __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, d16[v]) << s2v{6, 6}));
+      }
     }
     f4 Dh[5], Dd;
     {  // means and the next scale's input: the SAMPLES themselves (k * 2^-24); the mid-grey term 128 * sum(taps) is a constant
@@ -318,10 +322,14 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
           const s2v x = __builtin_bit_cast(s2v, xs), y = __builtin_bit_cast(s2v, ys);
           q[v] = __builtin_bit_cast(unsigned, s == 4 ? (s2v)(x * y + s2v{0x4000, 0x4000}) : (s2v)(x * y));
         } else {      // |v - 512| <= 512: 32-bit products of the sign-extended halves; the cross term gets 256 * 1024 added
-                      // so that its high digit (in [0, 512]) is unsigned like the squares'
+                      // so that its high digit (in [0, 512]) is unsigned like the squares'.  The products are formed times 64
+                      // (second factor pre-shifted, |.| <= 2^24): the base-1024 digits of x y then sit at bits 16.. and 6..15
+                      // of the register -- halfword-aligned, so that one v_perm_b32 packs the high digits of two pixels and
+                      // one v_perm_b32 + one packed shift the low ones (three shift / mask operations each before)
+          const unsigned yss = s == 2 ? r16s[v] : d16s[v];
           const int x0_ = (int)(short)(xs & 0xffffu), x1_ = (int)xs >> 16;
-          const int y0_ = (int)(short)(ys & 0xffffu), y1_ = (int)ys >> 16;
-          const int add = s == 4 ? (256 << 10) : 0;
+          const int y0_ = (int)(short)(yss & 0xffffu), y1_ = (int)yss >> 16;
+          const int add = s == 4 ? (256 << 16) : 0;
           p0[v] = (unsigned)(x0_ * y0_ + add);
           p1[v] = (unsigned)(x1_ * y1_ + add);
         }
@@ -330,7 +338,8 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
       {  // low digit: byte 0 of each 16-bit product / the low 10 bits of each 32-bit product
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          t[v] = W16 ? (((p1[v] << 16) & 0x03ff0000u) | (p0[v] & 0x3ffu)) : __builtin_amdgcn_perm(0u, q[v], 0x0c020c00u);
+          t[v] = W16 ? __builtin_bit_cast(unsigned, (us2v)(__builtin_bit_cast(us2v, __builtin_amdgcn_perm(p1[v], p0[v], 0x05040100u)) >> us2v{6, 6}))
+                     : __builtin_amdgcn_perm(0u, q[v], 0x0c020c00u);
         const h8 A = frag4(t[0], t[1], t[2], t[3]);
         Dh[s] = mma(A, T[W16 ? F_L9 : F_LO], z);
         Dh[s] = mma(A, T[W16 ? F_L9 + 1 : F_LO + 1], Dh[s]);
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
       {  // high digit: byte 1 / bits 10.. ; the cross term's offset (64 / 256) comes off in f16, exactly
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          t[v] = W16 ? (((p1[v] << 6) & 0xffff0000u) | (p0[v] >> 10)) : __builtin_amdgcn_perm(0u, q[v], 0x0c030c01u);
+          t[v] = W16 ? __builtin_amdgcn_perm(p1[v], p0[v], 0x07060302u) : __builtin_amdgcn_perm(0u, q[v], 0x0c030c01u);
           if (s == 4) t[v] = tiny_minus(t[v], W16 ? 0x8100 : 0x8040);
         }
         const h8 A = frag4(t[0], t[1], t[2], t[3]);
