@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--cpu-sample-frames", type=int, default=0, help="0: sized for ~12 s of CPU work")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(16, host cores) -- the 1-GPU share of the box")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="finish every clip (collect, score, pool) before the next one is queued (A/B partner of the default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -133,7 +135,7 @@ def main():
     _stage("clip generated and synchronised; creating the context")
 
     eng = FeatureEngine(w, h, bit_depth=bpc, n_planes=n_planes, features=feats, device=local_rank,
-                        max_batch=args.batch, result_capacity=max(F, 1024),
+                        max_batch=args.batch, result_capacity=max(2 * F, 1024),   # two clips in flight (see submit())
                         vif_enhn_gain_limit=model.vif_enhn_gain_limit,
                         adm_enhn_gain_limit=model.adm_enhn_gain_limit, vif_border=model.vif_border,
                         fixed_point=args.fixed_point)
@@ -144,9 +146,19 @@ def main():
     n_launch = -(-F // args.batch)
     per_launch = -(-F // n_launch)
 
-    def step():
-        eng.reset()
-        eng.submit_resident(a, F, ref_ptrs, dis_ptrs, row_pitch, frame_pitch, halo_ptr, row_pitch[0])
+    # A step = one clip: submit() queues its launches, finish() collects its records launch by launch, scores and pools.
+    # Consecutive clips alternate between two index ranges of the record ring, so clip k + 1 can be queued BEHIND clip k's
+    # kernels before the host has scored clip k's last launch -- what a job that scores clip after clip does; without it the
+    # GPU idles ~0.3 ms per 300-frame clip while the host scores the last launch and queues the next clip.  Every clip
+    # starts its own motion chain (pqa_set_motion_halo(NULL): motion of its first frame is 0) or takes the rank's halo frame.
+    def submit(k: int) -> int:
+        base = a + (k & 1) * F
+        if not halo_ptr:
+            eng.set_motion_halo(None)
+        eng.submit_resident(base, F, ref_ptrs, dis_ptrs, row_pitch, frame_pitch, halo_ptr, row_pitch[0])
+        return base
+
+    def finish(base: int):
         # records come back batch by batch: pqa_collect waits for ITS batch only (per-batch completion events), so the
         # host's share (feature epilogues + SVM) of batch k runs while the GPU works on batches k+1..  motion2 of a
         # frame needs its successor's motion: the last frame of what has arrived is scored with the next batch.
@@ -156,7 +168,7 @@ def main():
         clip_end = a + F == total            # this rank holds the clip's last frame (its motion2 is its own motion)
         for b0 in range(0, F, per_launch):   # the library cuts a run into equal launches (pqa_submit_device)
             n = min(per_launch, F - b0)
-            rec[b0:b0 + n] = eng.collect(a + b0, n)
+            rec[b0:b0 + n] = eng.collect(base + b0, n)
             e = b0 + n
             upto = e if (e == F and clip_end) else e - 1
             if upto > scored:
@@ -180,6 +192,12 @@ def main():
             result["vmaf"] = vmaf
             result["pooled"] = M.pool(vmaf)
 
+    n_steps = [0]
+
+    def step():                       # one clip on its own: submitted, collected, scored
+        n_steps[0] += 1
+        finish(submit(n_steps[0]))
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -192,9 +210,19 @@ def main():
         eng.profile_enable([0])       # HIP events around the dominant kernel only (vif_stat_s0) while timing
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-        _stage(f"timed step {i + 1}/{args.steps} submitted and collected")
+    if args.no_pipeline:
+        for i in range(args.steps):
+            step()
+            _stage(f"timed step {i + 1}/{args.steps} submitted and collected")
+    else:                             # exactly K clips, every launch and every score inside the timed region
+        k0 = n_steps[0] + 1
+        pending = submit(k0)
+        for i in range(args.steps):
+            nxt = submit(k0 + i + 1) if i + 1 < args.steps else None
+            finish(pending)
+            pending = nxt
+            _stage(f"timed step {i + 1}/{args.steps} collected" + ("" if nxt is None else "; the next one is queued"))
+        n_steps[0] += args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     _stage("timed region closed")
@@ -231,6 +259,7 @@ def main():
                                    f"{' + PSNR/SSIM all planes' if side else ''}"
                                    f"{f' [--fixed-point {args.fixed_point}: libvmaf integer arithmetic]' if args.fixed_point else ''}",
                        "frames_per_gpu": F, "frames_total": total, "batch": args.batch, "frames_per_launch": per_launch,
+                       "clips_pipelined": not args.no_pipeline,
                        "parallelism": f"frame-shard x{world}, 1-frame motion halo, all-gather of records + of scores"},
             "pooled_vmaf_mean": round(result["pooled"]["mean"], 6),
         }
