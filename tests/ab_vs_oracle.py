@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How far are two builds of libpqa_vmaf.so from the f64 oracle (and how far is the f32 oracle itself)?  For changes that
 trade arithmetic for speed: a build may move WITHIN the f32 oracle's own distance from f64, not beyond it.
-usage: ab_vs_oracle.py A.so B.so            (test tooling: imports oracle/, never part of the product path)"""
+usage: python tests/ab_vs_oracle.py A.so B.so      (test tooling like fuzz_parity.py: it calls the oracle; not collected by pytest)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
