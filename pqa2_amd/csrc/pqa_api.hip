@@ -1176,9 +1176,11 @@ int pqa_submit_surfaces(pqa_ctx* c, int64_t first_index, int32_t n_frames, const
       c->halo_armed = true;
     }
   }
+  const int n_launch = (n_frames + c->B - 1) / c->B;   // equal launches, as in pqa_submit_device
+  const int per = n_launch ? (n_frames + n_launch - 1) / n_launch : 0;
   for (int done = 0; done < n_frames;) {
     if (c->cancelled.load()) return fail(c, PQA_ECANCELLED, "cancelled");
-    const int n = n_frames - done < c->B ? n_frames - done : c->B;
+    const int n = n_frames - done < per ? n_frames - done : per;
     pqa_device_clip r{}, d{};
     const pqa_surface_clip* side[2] = {ref, dis};
     pqa_device_clip* out[2] = {&r, &d};
