@@ -37,13 +37,13 @@ inline int vif_tiles_y(int h) { return (h + kVifTileH - 1) / kVifTileH; }
 // *n_partials (nullable) receives the number of (num, den) pairs per frame the launch wrote: vif_tiles_x * vif_tiles_y for
 // the tiled kernels, one per wave segment for the march kernel of scale 0 (vif_march.hip); the finalize stage sums that many.
 // s0_mode: which kernel scale 0 runs (read once per context from PQA_VIF_MFMA in pqa_create: A/B runs and the tests that
-// compare the paths): VIF_S0_AUTO = the march kernel (8- and 10-bit clips; 12-bit clips run the VALU kernel);
+// compare the paths): VIF_S0_AUTO = the march kernel (8-, 10- and 12-bit clips);
 // VIF_S0_VALU = VALU only.
 enum : int { VIF_S0_VALU = 0, VIF_S0_AUTO = 1 };
 hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames,
                            int w, int h, float inv_scale, float gain_limit, int border101, double* partials,
                            MutPlaneRun next_ref, MutPlaneRun next_dis, int s0_mode = VIF_S0_AUTO, int* n_partials = nullptr);
-// Scale 0 of 8- and 10-bit clips, both filter passes on the f16 matrix cores (vif_march.hip).  vif_march_prepare uploads its tap
+// Scale 0 (8-, 10-, 12-bit clips: `bits`), both filter passes on the f16 matrix cores (vif_march.hip).  vif_march_prepare uploads its tap
 // table once per device (pqa_create does; synchronous, idempotent; a device that does not keep f16 denormals -- probed once,
 // the operand encoding leans on them -- gets no table and scale 0 stays on the VALU kernel); launch_vif_s0_march returns false when it cannot take
 // the planes (no table, pitches the stores cannot take) and launch_vif_stat then falls back to the tiled kernels.
@@ -55,7 +55,7 @@ int vif_march_partials_max(int w, int h);
 int vif_march_table(uint16_t* out, int capacity_halfwords);
 // {16-column stripes, 16-row blocks, blocks per segment, segments, pass-1 MFMAs per block, pass-2 MFMAs per block} of a w x h frame
 void vif_march_shape(int w, int h, int* out6);
-bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
+bool launch_vif_s0_march(hipStream_t stream, Elem elem, int bits, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
                          int border101, double* partials, MutPlaneRun next_ref, MutPlaneRun next_dis, int* n_partials,
                          hipError_t* err);
 // Fixed-point VIF (integer_vif.c arithmetic, vif_fixed.hip): same tiling; partials are [n_frames][tiles][8] int64

@@ -941,7 +941,7 @@ int pqa_create(const pqa_config* cfg, pqa_ctx** out) {
     CREATE_TRY(dev_alloc(c, &c->adm_div_lut, lut.size()));
     CREATE_HIP(hipMemcpy(c->adm_div_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
-  if ((cfg->features & PQA_FEAT_VIF) && !c->vif_fixed && cfg->bit_depth <= 10) CREATE_HIP(vif_march_prepare());
+  if ((cfg->features & PQA_FEAT_VIF) && !c->vif_fixed) CREATE_HIP(vif_march_prepare());
   if (c->vif_fixed) {
     std::vector<uint16_t> lut(32768);
     vif_fixed_log2_table(lut.data());

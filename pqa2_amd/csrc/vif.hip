@@ -17,8 +17,8 @@
 //      stage (finalize.hip) keeps a frame's record independent of batch size and rank count.
 // HBM traffic: the two input planes once (halo re-reads hit L2) + the half-resolution planes written once.
 //
-// Which kernel runs where (launch_vif_stat at the bottom): scales 1-3 and scale 0 of 12-bit clips: vif_stat_kernel (VALU);
-// scale 0 of 8- and 10-bit clips: vif_s0_march_kernel in vif_march.hip (both filter passes on the f16 matrix cores), with
+// Which kernel runs where (launch_vif_stat at the bottom): scales 1-3: vif_stat_kernel (VALU);
+// scale 0 (8-, 10- and 12-bit clips): vif_s0_march_kernel in vif_march.hip (both filter passes on the f16 matrix cores), with
 // vif_stat_kernel as its test partner (PQA_VIF_MFMA=0) and its fallback (no tap table, next-scale planes whose pitches its
 // 16-byte stores cannot take).  The round-2 kernel that put only the vertical pass on the matrix cores left the build in
 // round 4: tools/experiments/vif_s0_mfma_round2.hip.txt.
@@ -370,11 +370,11 @@ hipError_t launch_vif_stat(hipStream_t stream, int scale, Elem elem, PlaneRun re
                            MutPlaneRun next_ref, MutPlaneRun next_dis, int s0_mode, int* n_partials) {
   if (n_partials) *n_partials = vif_tiles_x(scale, w) * vif_tiles_y(h);
   if (n_frames <= 0) return hipSuccess;
-  // (10 bit is recognised by its sample scale 1/4; 12-bit clips have squares of 22 bits, three digits: tiled kernels)
-  if (scale == 0 && (elem == ELEM_U8 || (elem == ELEM_U16 && inv_scale == 0.25f)) && s0_mode == VIF_S0_AUTO && next_ref.base &&
-      next_dis.base) {
+  // (the bit depth of 16-bit elements is recognised by the sample scale: 1/4 = 10 bit, 1/16 = 12 bit)
+  const int bits = elem == ELEM_U8 ? 8 : (elem == ELEM_U16 && inv_scale == 0.25f) ? 10 : (elem == ELEM_U16 && inv_scale == 0.0625f) ? 12 : 0;
+  if (scale == 0 && bits && s0_mode == VIF_S0_AUTO && next_ref.base && next_dis.base) {
     hipError_t err = hipSuccess;
-    if (launch_vif_s0_march(stream, elem, ref, dis, n_frames, w, h, gain_limit, border101, partials, next_ref, next_dis, n_partials, &err))
+    if (launch_vif_s0_march(stream, elem, bits, ref, dis, n_frames, w, h, gain_limit, border101, partials, next_ref, next_dis, n_partials, &err))
       return err;
     if (n_partials) *n_partials = vif_tiles_x(scale, w) * vif_tiles_y(h);
   }

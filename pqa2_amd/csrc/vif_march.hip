@@ -71,7 +71,8 @@ enum : int {
   F_W = 16,    // 16,17  as F_V with K order {current block rows, previous block rows}
   F_WD = 18,   // 18,19  as F_VD in that order
   F_L9 = 20,   // 20,21  pass 1 of 10-bit clips, c * 2^9 in two pieces (low digits base 1024)
-  kMarchFrags = 22
+  F_L8 = 22,   // 22,23  pass 1 of 12-bit clips, c * 2^8 in two pieces (low digits base 2048)
+  kMarchFrags = 24
 };
 
 struct MarchArgs {
@@ -157,10 +158,16 @@ __device__ __forceinline__ void stat_pair(StatAcc& s, const f2 mu1, const f2 mu2
 // and the cross term of v - 512 (|.| <= 512, products of up to 19 bits) come from 32-bit multiplies and are split into
 // base-1024 digits (hi <= 512, lo < 1024); the low digit planes use pieces of c * 2^9.  Every plane then leaves pass 1 as
 // 2^-13 (means) or 2^-15 (squares) of its integer sum, and the sample scale (1/4 on the means, 1/16 on the squares) joins
-// the split's factor.  12-bit clips (squares of 22 bits: three digits) stay on the tiled kernels.
-template <typename S>
+// the split's factor.  12-bit clips: the B12 instance below.
+// B12 (with S = uint16_t): 12-bit samples (x = v / 16 - 128 = (v - 2048) / 16).  A sample is no longer its own f16 pattern (k <=
+// 2048 only), so the mean planes take the CENTRED sample v - 2048 as a sign-magnitude pattern (|.| <= 2048; the mid-grey
+// terms of the means and of the next scale's input are then zero); squares and cross term of v - 2048 (up to 2^22) are split
+// into base-2048 digits: the high digit of a square is in [0, 2048], the cross term's in [-2047, 2048] (floor), again a
+// sign-magnitude pattern; the low digit planes use pieces of c * 2^8.
+template <typename S, bool B12 = false>
 __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(const MarchArgs a) {
   constexpr bool W16 = sizeof(S) == 2;
+  static_assert(W16 || !B12, "12-bit samples are 16-bit elements");
   constexpr int ES = (int)sizeof(S);
   const int tid = threadIdx.x;
 #if PQA_MARCH_LDS_TABLES
@@ -203,7 +210,8 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
   for (int f = 0; f < kMarchFrags; ++f) {
     const bool in_lds = PQA_MARCH_LDS_TABLES && ((f >= F_DR && f < F_DR + 6) || (f >= F_VD && f < F_VD + 2) || (f >= F_WD && f < F_WD + 2));
     const bool third = f == F_HI + 2 || f == F_LO + 2 || f == F_DR + 2 || f == F_DD + 2;
-    const bool unused = (W16 ? false : f >= F_L9) || (PQA_MARCH_TAP_PIECES < 3 && third);
+    const bool needed = f < F_L9 || (f < F_L8 ? (W16 && !B12) : B12);   // F_L9: 10-bit clips only; F_L8: 12-bit clips only
+    const bool unused = !needed || (PQA_MARCH_TAP_PIECES < 3 && third);
     if (!in_lds && !unused) T[f] = __builtin_bit_cast(h8, a.tab[f * 64 + lane]);
   }
 #if PQA_MARCH_LDS_TABLES
@@ -275,8 +283,13 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
     const f4 z = f4{0.0f, 0.0f, 0.0f, 0.0f};
     // 16-bit lanes {col 2v, col 2v+1} of this lane's 8 columns.  8 bit: byte -> zero-extended half (one v_perm_b32 each);
     // 10 bit: the loaded dwords as they are.  r16 / d16: the same minus mid-grey, as signed 16-bit integers.
-    constexpr short MID = W16 ? 512 : 128;
-    unsigned ru[4], du[4], r16[4], d16[4], r16s[4], d16s[4];
+    constexpr short MID = W16 ? (B12 ? 2048 : 512) : 128;
+    // two's-complement halves with |.| <= 2048 -> sign-magnitude f16 patterns (+-k * 2^-24)
+    const auto sign_mag = [](const unsigned x) -> unsigned {
+      const s2v v = __builtin_bit_cast(s2v, x), n = s2v{0, 0} - v;
+      return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, n)) | (x & 0x80008000u);
+    };
+    unsigned ru[4], du[4], r16[4], d16[4], r16s[4], d16s[4], r16t[4], d16t[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       if constexpr (W16) {
@@ -289,9 +302,17 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
       }
       r16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, ru[v]) - s2v{MID, MID});
       d16[v] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s2v, du[v]) - s2v{MID, MID});
-      if constexpr (W16) {   // 64 (v - 512) in [-2^15, 2^15): the second factor of every product, see below
+      if constexpr (W16 && !B12) {   // 64 (v - 512) in [-2^15, 2^15): the second factor of every product, see below
         r16s[v] = __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, r16[v]) << s2v{6, 6}));
         d16s[v] = __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, d16[v]) << s2v{6, 6}));
+      }
+      if constexpr (B12) {           // 12 bit: 8 (v - 2048) as the second factor and 4 (v - 2048) as the first (x 32 together)
+        r16s[v] = __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, r16[v]) << s2v{3, 3}));
+        d16s[v] = __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, d16[v]) << s2v{3, 3}));
+        r16t[v] = __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, r16[v]) << s2v{2, 2}));
+        d16t[v] = __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, d16[v]) << s2v{2, 2}));
+        ru[v] = sign_mag(r16[v]);    // the mean planes' operand: the centred sample
+        du[v] = sign_mag(d16[v]);
       }
     }
     f4 Dh[5], Dd;
@@ -316,7 +337,7 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
       unsigned q[4], p0[4], p1[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const unsigned xs = s == 3 ? d16[v] : r16[v], ys = s == 2 ? r16[v] : d16[v];
+        const unsigned xs = B12 ? (s == 3 ? d16t[v] : r16t[v]) : (s == 3 ? d16[v] : r16[v]), ys = s == 2 ? r16[v] : d16[v];
         if (!W16) {   // 16-bit products; the cross term is signed: + 64 * 256 makes both digits unsigned (one
                       // v_pk_mad_u16), the 64 comes off below
           const s2v x = __builtin_bit_cast(s2v, xs), y = __builtin_bit_cast(s2v, ys);
@@ -329,7 +350,7 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
           const unsigned yss = s == 2 ? r16s[v] : d16s[v];
           const int x0_ = (int)(short)(xs & 0xffffu), x1_ = (int)xs >> 16;
           const int y0_ = (int)(short)(yss & 0xffffu), y1_ = (int)yss >> 16;
-          const int add = s == 4 ? (256 << 16) : 0;
+          const int add = (s == 4 && !B12) ? (256 << 16) : 0;   // (12 bit: the cross term's high digit stays signed)
           p0[v] = (unsigned)(x0_ * y0_ + add);
           p1[v] = (unsigned)(x1_ * y1_ + add);
         }
@@ -338,17 +359,17 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
       {  // low digit: byte 0 of each 16-bit product / the low 10 bits of each 32-bit product
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          t[v] = W16 ? __builtin_bit_cast(unsigned, (us2v)(__builtin_bit_cast(us2v, __builtin_amdgcn_perm(p1[v], p0[v], 0x05040100u)) >> us2v{6, 6}))
+          t[v] = W16 ? __builtin_bit_cast(unsigned, (us2v)(__builtin_bit_cast(us2v, __builtin_amdgcn_perm(p1[v], p0[v], 0x05040100u)) >> us2v{B12 ? 5 : 6, B12 ? 5 : 6}))
                      : __builtin_amdgcn_perm(0u, q[v], 0x0c020c00u);
         const h8 A = frag4(t[0], t[1], t[2], t[3]);
-        Dh[s] = mma(A, T[W16 ? F_L9 : F_LO], z);
-        Dh[s] = mma(A, T[W16 ? F_L9 + 1 : F_LO + 1], Dh[s]);
+        Dh[s] = mma(A, T[B12 ? F_L8 : W16 ? F_L9 : F_LO], z);
+        Dh[s] = mma(A, T[B12 ? F_L8 + 1 : W16 ? F_L9 + 1 : F_LO + 1], Dh[s]);
       }
       {  // high digit: byte 1 / bits 10.. ; the cross term's offset (64 / 256) comes off in f16, exactly
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           t[v] = W16 ? __builtin_amdgcn_perm(p1[v], p0[v], 0x07060302u) : __builtin_amdgcn_perm(0u, q[v], 0x0c030c01u);
-          if (s == 4) t[v] = tiny_minus(t[v], W16 ? 0x8100 : 0x8040);
+          if (s == 4) t[v] = B12 ? sign_mag(t[v]) : tiny_minus(t[v], W16 ? 0x8100 : 0x8040);
         }
         const h8 A = frag4(t[0], t[1], t[2], t[3]);
         Dh[s] = mma(A, T[F_HI], Dh[s]);
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(kBlock, PQA_MARCH_OCC) void vif_s0_march_kernel(con
     // and the squares times 2^-15 (base-1024 digits, low pieces c * 2^9), both still in sample units (x 4 and x 16).
     // Into pass 2: means as natural / 16, squares as natural, the next scale's input as natural.
     // The means were filtered as samples: sum c (x - 128) = sum c x - 128 sum c, with sum c the sum of the taps AS APPLIED (the pieces).
-    constexpr float KM = W16 ? 128.0f : 512.0f, KS = W16 ? 2048.0f : 8192.0f, KD = W16 ? 16.0f : 64.0f;
+    constexpr float KM = B12 ? 32.0f : W16 ? 128.0f : 512.0f, KS = B12 ? 256.0f : W16 ? 2048.0f : 8192.0f, KD = B12 ? 4.0f : W16 ? 16.0f : 64.0f;
     split4<H>(Dh[0], KM, a.mean_off, P.hi[0], P.lo[0]);
     split4<H>(Dh[1], KM, a.mean_off, P.hi[1], P.lo[1]);
     split4<H>(Dh[2], KS, 0.0f, P.hi[2], P.lo[2]);
@@ -499,6 +520,7 @@ bool build_table(uint16_t* out /* [kMarchFrags][64][8] */) {
       if (pieces(c * 524288.0, 3, o + F_HI * stride, stride) != 0.0) exact = false;
       if (pieces(c * 2048.0, 3, o + F_LO * stride, stride) != 0.0) exact = false;
       pieces(c * 512.0, 2, o + F_L9 * stride, stride);   // the 10-bit low digits weigh 2^-10 of the signal: 22 bits of the tap
+      pieces(c * 256.0, 2, o + F_L8 * stride, stride);   // the 12-bit low digits (base 2048)
       // next scale: N slot n = even column 2 (n & 7) (window column 2 (n & 7) + 8) of ref (n < 8) or dis (n >= 8)
       const int t9 = wc - (2 * (n & 7) + 4);
       const double cd = (t9 >= 0 && t9 <= 8) ? (double)c9[t9] : 0.0;
@@ -622,13 +644,13 @@ hipError_t vif_march_prepare() {
   return hipSuccess;
 }
 
-bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
+bool launch_vif_s0_march(hipStream_t stream, Elem elem, int bits, PlaneRun ref, PlaneRun dis, int n_frames, int w, int h, float gain_limit,
                          int border101, double* partials, MutPlaneRun next_ref, MutPlaneRun next_dis, int* n_partials,
                          hipError_t* err) {
   MarchArgs a{};
   a.tab = device_tab();
   if (!a.tab) return false;
-  if (elem != ELEM_U8 && elem != ELEM_U16) return false;
+  if (!((elem == ELEM_U8 && bits == 8) || (elem == ELEM_U16 && (bits == 10 || bits == 12)))) return false;
   const int es = elem == ELEM_U16 ? 2 : 1;
   if (ref.row_pitch * es >= (1ll << 31) || dis.row_pitch * es >= (1ll << 31)) return false;
   a.ref = ref.base; a.dis = dis.base;
@@ -660,8 +682,9 @@ bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun d
     double s17 = 0.0, s9 = 0.0;
     for (int k = 0; k < 17; ++k) s17 += applied(c17[k], 2048.0);
     for (int k = 0; k < 9; ++k) s9 += applied(c9[k], 262144.0);
-    a.mean_off = (float)(-128.0 * s17 / 16.0);
-    a.dec_off = (float)(-128.0 * s9);
+    // (12-bit clips are filtered as CENTRED samples: nothing to take off)
+    a.mean_off = bits == 12 ? 0.0f : (float)(-128.0 * s17 / 16.0);
+    a.dec_off = bits == 12 ? 0.0f : (float)(-128.0 * s9);
   }
   {
     int shape[6];
@@ -670,8 +693,10 @@ bool launch_vif_s0_march(hipStream_t stream, Elem elem, PlaneRun ref, PlaneRun d
   }
   a.n_part = a.n_cbg * 4 * a.n_seg;
   if (n_partials) *n_partials = a.n_part;
-  if (elem == ELEM_U16) hipLaunchKernelGGL(vif_s0_march_kernel<uint16_t>, dim3(a.n_cbg * a.n_seg, n_frames), dim3(kBlock), 0, stream, a);
-  else hipLaunchKernelGGL(vif_s0_march_kernel<uint8_t>, dim3(a.n_cbg * a.n_seg, n_frames), dim3(kBlock), 0, stream, a);
+  const dim3 grid(a.n_cbg * a.n_seg, n_frames), block(kBlock);
+  if (bits == 12) hipLaunchKernelGGL((vif_s0_march_kernel<uint16_t, true>), grid, block, 0, stream, a);
+  else if (elem == ELEM_U16) hipLaunchKernelGGL((vif_s0_march_kernel<uint16_t, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((vif_s0_march_kernel<uint8_t, false>), grid, block, 0, stream, a);
   *err = hipGetLastError();
   return true;
 }

@@ -9,7 +9,8 @@ from oracle.oracle import Oracle
 from pqa2_amd import _native as N, synth
 
 CASES = [(3840, 2160, 8, 2, "natural"), (1920, 1080, 8, 3, "natural"), (1920, 1080, 8, 2, "flat"), (1280, 720, 10, 3, "natural"),
-         (1920, 1080, 10, 2, "dark"), (640, 360, 8, 4, "natural"), (200, 120, 8, 4, "natural")]
+         (1920, 1080, 10, 2, "dark"), (1920, 1080, 12, 2, "natural"), (1280, 720, 12, 2, "dark"), (640, 360, 8, 4, "natural"),
+         (200, 120, 8, 4, "natural")]
 
 
 def clip(w, h, bpc, n, kind):

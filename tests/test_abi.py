@@ -145,7 +145,7 @@ def test_march_kernels_fit_three_waves_per_simd_without_scratch(tmp_path):
     kernels = re.findall(r"^; Function info:.*?^; Occupancy: (\d+)", text, re.S | re.M)
     scratch = [int(x) for x in re.findall(r"^; ScratchSize: (\d+)", text, re.M)]
     vgprs = [int(x) for x in re.findall(r"^; TotalNumVgprs: (\d+)", text, re.M)]
-    assert len(scratch) >= 2 and all(s == 0 for s in scratch), scratch          # the 8-bit and the 10-bit instance
+    assert len(scratch) >= 3 and all(s == 0 for s in scratch), scratch          # the 8-, 10- and 12-bit instances
     assert all(v <= 168 for v in vgprs), vgprs                                   # 512 / 3 waves, 8-register granules
     assert "Folded Reload" not in text and "Folded Spill" not in text
 

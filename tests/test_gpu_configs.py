@@ -465,11 +465,12 @@ def test_rccl_gather_of_device_records_with_one_rank(tmp_path):
 
 # ---- VIF scale 0 on the matrix cores (vif_s0_march_kernel) vs the VALU kernel and the oracle -----------------------
 @pytest.mark.parametrize("w,h,bpc", [(488, 40, 8), (489, 41, 8), (736, 48, 8), (1000, 200, 8), (1281, 721, 8), (1920, 1080, 8),
-                                     (64, 48, 10), (489, 41, 10), (1000, 200, 10), (1920, 1080, 10)])
+                                     (64, 48, 10), (489, 41, 10), (1000, 200, 10), (1920, 1080, 10),
+                                     (64, 48, 12), (489, 41, 12), (1000, 200, 12), (1920, 1080, 12)])
 def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
     """Scale 0 on the matrix cores against the VALU kernel and the oracle: the march kernel (vif_march.hip: first pass on
-    exact integer digit planes x three-piece taps, second pass on two-piece f16 splits of the f32 intermediates), 8 and 10
-    bit.  Geometries from 64 x 48 up to 1080p, odd sizes included.  The paths must agree far inside the oracle bar,
+    exact integer digit planes x two-piece (22-bit) taps, second pass on two-piece f16 splits of the f32 intermediates), 8, 10
+    and -- since round 4's last session -- 12 bit (centred samples and the cross term's high digit as sign-magnitude patterns).  Geometries from 64 x 48 up to 1080p, odd sizes included.  The paths must agree far inside the oracle bar,
     PQA_VIF_MFMA=0 (read at pqa_create) must really switch the path off, and a caller pitch the wide loads cannot take
     (odd) must not change a bit: the march kernel then loads sample by sample.  (The round-2 kernel that was this test's
     third party until round 3 left the build: tools/experiments/vif_s0_mfma_round2.hip.txt.)"""
@@ -480,9 +481,11 @@ def test_vif_mfma_path_matches_valu_path_and_oracle(oracle32, w, h, bpc):
     from pqa2_amd import _native as N
     n = 2
     refs, diss = synth.make_clip(w, h, n, bpc, chroma=False)
-    if bpc > 8:   # the extremes of the sample range in both clips: digit planes at their limits (0 -> -512, 1023 -> 511)
-        refs[0][0][:4, :8] = 0; diss[0][0][:4, :8] = 1023
-        refs[1][0][-3:, -9:] = 1023; diss[1][0][-3:, -9:] = 1023
+    if bpc > 8:   # the extremes of the sample range in both clips: digit planes at their limits (0 -> -512, 1023 -> 511;
+        top = (1 << bpc) - 1   # 12 bit: 0 -> -2048 whose square 2^22 is the one high digit of 2048, 4095 -> 2047)
+        refs[0][0][:4, :8] = 0; diss[0][0][:4, :8] = top
+        refs[1][0][-3:, -9:] = top; diss[1][0][-3:, -9:] = top
+        refs[1][0][:3, :9] = 0; diss[1][0][:3, :9] = 0
     else:
         refs[0][0][:4, :8] = 0; diss[0][0][:4, :8] = 255
         refs[1][0][-3:, -9:] = 255; diss[1][0][-3:, -9:] = 255
@@ -552,7 +555,41 @@ def test_worst_known_hd_flip_case_stays_bounded():
     assert np.abs(vm(got) - vm(d["exp"])).max() < 0.012
 
 
-@pytest.mark.parametrize("bpc", [8, 10])
+_ONLY_12_BIT = r"""
+import os, sys
+import numpy as np
+from pqa2_amd import synth, _native as N
+from pqa2_amd.engine import FeatureEngine
+w, h, n = 320, 180, 2
+refs, diss = synth.make_clip(w, h, n, 12, chroma=False)
+out = []
+for mode in ("1", "0"):
+    os.environ["PQA_VIF_MFMA"] = mode
+    with FeatureEngine(w, h, bit_depth=12, features=N.FEAT_VIF) as eng:
+        for i in range(n):
+            eng.submit(i, refs[i], diss[i])
+        out.append(eng.collect(0, n)[:, :8])
+assert not np.array_equal(out[0].view(np.uint64), out[1].view(np.uint64)), "a 12-bit context alone did not get the march kernel"
+assert (np.abs(out[0] - out[1]) / np.abs(out[1])).max() < 2e-6
+print("only-12-bit ok")
+"""
+
+
+def test_a_12_bit_context_alone_gets_the_march_kernel():
+    """The tap table of the march kernel is uploaded by pqa_create.  It once was only for 8- and 10-bit contexts, so a
+    process whose FIRST context was 12 bit silently ran the VALU kernel (and every test passed, because an earlier test had
+    created an 8-bit context in the same process).  A fresh process with nothing but a 12-bit context: PQA_VIF_MFMA=0 must
+    change the records (by rounding only)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ONLY_12_BIT], env=dict(os.environ, PYTHONPATH=root), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "only-12-bit ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_march_kernel_takes_any_base_alignment_and_pitch_bit_for_bit(bpc):
     """(adm_march_kernel and motion_march_kernel -- two samples per lane and load -- are held to the same: round 4.)
     vif_s0_march_kernel loads 8 samples per lane with one 8 / 16-byte load when bases and pitches allow it and sample by

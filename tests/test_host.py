@@ -360,7 +360,7 @@ def _march_table():
     need = -lib.pqa_debug_vif_march_table(None, 0)
     buf = np.zeros(need, np.uint16)
     n = lib.pqa_debug_vif_march_table(buf.ctypes.data, need)
-    assert n == 22, n                                              # 0 would mean: a tap does not split exactly into f16 pieces
+    assert n == 24, n                                              # 0 would mean: a tap does not split exactly into f16 pieces
     return buf.view(np.float16).reshape(n, 64, 8).astype(np.float64)   # [fragment][lane][element], exact in f64
 
 
@@ -387,7 +387,7 @@ def test_march_tap_tables_replayed_in_numpy_are_the_separable_gaussian():
     f32 tap exactly, the two the kernel multiplies (PQA_MARCH_TAP_PIECES = 2 since round 4) and the two of a pass-2 tap to 22
     bits of it -- and the next scale's 9-tap even-row / even-column planes for ref and dis."""
     T = _march_table()
-    F_HI, F_LO, F_DR, F_DD, F_V, F_VD, F_W, F_WD, F_L9 = 0, 3, 6, 9, 12, 14, 16, 18, 20
+    F_HI, F_LO, F_DR, F_DD, F_V, F_VD, F_W, F_WD, F_L9, F_L8 = 0, 3, 6, 9, 12, 14, 16, 18, 20, 22
     c17, c9 = _gauss(17), _gauss(9)
     rng = np.random.default_rng(5)
 
@@ -399,6 +399,8 @@ def test_march_tap_tables_replayed_in_numpy_are_the_separable_gaussian():
     l9 = sum(_as_B(T[F_L9 + p]) for p in range(2))                     # c * 2^9, two pieces (22 bits of the tap)
     assert np.array_equal(X @ lo, want * 2048.0) and np.array_equal(X @ hi, want * 524288.0)
     assert np.abs(X @ l9 / 512.0 - want).max() < 2e-6 * np.abs(want).max()
+    l8 = sum(_as_B(T[F_L8 + p]) for p in range(2))                     # c * 2^8, two pieces: the 12-bit low digits
+    assert np.abs(X @ l8 / 256.0 - want).max() < 2e-6 * np.abs(want).max()
     # what the kernel multiplies: the first two pieces -- the SAME 22 bits of the tap in both tables (pieces scale with the
     # power of two), a filter whose taps differ from the f32 ones by less than 2^-22 each
     lo2 = sum(_as_B(T[F_LO + p]) for p in range(2))
