@@ -583,9 +583,9 @@ void vif_march_shape(int w, int h, int* out) {
 #define PQA_MARCH_WAVES_SCALED 1
 #endif
   // PQA_MARCH_WAVES_SCALED: the target follows the frame's pixel count (the automatic batch keeps the BYTES per launch
-  // constant, so a launch of smaller frames has as many waves with proportionally fewer per frame): 1080p marches
-  // segments of 17 blocks instead of 8 -- 18 / 17 instead of 9 / 8 on pass 1 -- VIF chain +7 %, whole path +4.9 % at 1080p,
-  // +3 % / +1 % at 720p (profiles/r06c_march_segments_ab.txt); 2160p and up are unchanged
+  // constant, so a launch of smaller frames has as many waves with proportionally fewer per frame; never under 192 waves per
+  // frame): 2160p and 1080p march 34-block segments (35 / 34 on pass 1).  With a fixed target 1080p had 8-block segments
+  // (9 / 8): VIF chain +7 %, whole path +4.9 % at 1080p, +3 % / +1 % at 720p (profiles/r06c_march_segments_ab.txt)
   const int want_waves = PQA_MARCH_WAVES_SCALED
       ? (int)fmax(192.0, PQA_MARCH_WAVES_PER_FRAME * ((double)w * h) / (3840.0 * 2160.0)) : PQA_MARCH_WAVES_PER_FRAME;
   while (seg > kMinSegBlocks && n_cbg * 4 * ((row_blocks + seg - 1) / seg) < want_waves) seg = (seg + 1) / 2;
